@@ -1,0 +1,275 @@
+"""CPU restatement of the DENet head hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  ``denet_amd`` never imports anything under ``oracle/``.
+
+It restates, with stock PyTorch CPU ops in the reference's op order, what the
+reference head computes (citations are into /root/reference).  It is pinned
+against golden fixtures captured from the reference's own code run in the
+build container (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``); the
+reference has no test suite of its own for this path.
+
+Nothing here is copied from the reference: the functions are written from the
+algorithm description in SURVEY.md §8a and checked against the fixtures.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS_POOL = 1e-3          # model/common.py:170 (eps of MaskedAveragePooling.forward)
+IGNORE = 255             # loss/losses.py:19,47
+FOCAL_ALPHA = 0.25       # loss/losses.py:47
+FOCAL_GAMMA = 2
+
+
+# --------------------------------------------------------------------------
+# index rules (verified against ATen by the fixtures)
+# --------------------------------------------------------------------------
+def nearest_src_index(out_size: int, in_size: int) -> np.ndarray:
+    """F.interpolate(mode='nearest') source index for each destination index.
+    src = min(floor(dst * fp32(in/out)), in-1)    (model/common.py:190,238)."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    dst = np.arange(out_size, dtype=np.float32)
+    src = np.floor(dst * scale).astype(np.int64)
+    return np.minimum(src, in_size - 1)
+
+
+def bilinear_taps(out_size: int, in_size: int):
+    """align_corners=True bilinear taps (trainer/trainers.py:955-956):
+    src = dst*(in-1)/(out-1), i0=floor(src), i1=min(i0+1,in-1), frac=src-i0."""
+    if out_size > 1:
+        scale = np.float32(in_size - 1) / np.float32(out_size - 1)
+    else:
+        scale = np.float32(0)
+    src = np.arange(out_size, dtype=np.float32) * scale
+    i0 = np.minimum(src.astype(np.int64), in_size - 1)
+    i1 = np.minimum(i0 + 1, in_size - 1)
+    frac = (src - i0.astype(np.float32)).astype(np.float32)
+    return i0, i1, frac
+
+
+# --------------------------------------------------------------------------
+# K1: mask resize + masked pooling      (model/common.py:188-198, 234-246)
+# --------------------------------------------------------------------------
+def resize_mask(Ys: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """[B,H,W] int -> [B,1,h,w] float, nearest."""
+    return F.interpolate(Ys.unsqueeze(1).float(), size=(h, w), mode="nearest")
+
+
+def gam_attention(Fs: torch.Tensor, Ys: torch.Tensor) -> torch.Tensor:
+    """att = mean over all h*w positions of mask*Fs  -> [B,c,1,1]
+    (GAM.forward, model/common.py:241-243)."""
+    h, w = Fs.shape[-2:]
+    return F.adaptive_avg_pool2d(resize_mask(Ys, h, w) * Fs, (1, 1))
+
+
+def gate(att, p, gate_mask=None):
+    """g = sigmoid(dropout(conv2(relu(conv1(att)))))  (model/common.py:225-232).
+    gate_mask, if given, is the already-scaled dropout multiplier [B,c,1,1]."""
+    z = F.conv2d(att, p["gam.gate.0.weight"], p["gam.gate.0.bias"])
+    z = F.relu(z)
+    z = F.conv2d(z, p["gam.gate.2.weight"], p["gam.gate.2.bias"])
+    if gate_mask is not None:
+        z = z * gate_mask
+    return torch.sigmoid(z)
+
+
+def masked_avg_pool_project(Fs_g, Ys, p):
+    """(sum(mask*F)/(sum(mask)+1e-3)) -> 1x1 conv   (model/common.py:188-196)."""
+    h, w = Fs_g.shape[-2:]
+    m = resize_mask(Ys, h, w)
+    num = torch.sum(m * Fs_g, dim=(2, 3), keepdim=True)
+    den = torch.sum(m, dim=(2, 3), keepdim=True)
+    proto = num / (den + EPS_POOL)
+    return F.conv2d(proto, p["map.linear.weight"], p["map.linear.bias"])
+
+
+# --------------------------------------------------------------------------
+# K2: dynamic extension of the class-weight matrix (model/common.py:304-368)
+# --------------------------------------------------------------------------
+def extend_weights(Fs, Ys, labels, p, gate_mask=None, weight_mask=None):
+    """Fs [N,way,shot,c,h,w], Ys [N,way,shot,H,W], labels [N,way] ->
+    weights [N,K,c].  gate_mask [N*way*shot,c,1,1] and weight_mask [N,K,c]
+    are the scaled dropout multipliers (train mode) or None (eval)."""
+    N, way, shot, c, h, w = Fs.shape
+    B = N * way * shot
+    Fm = Fs.reshape(B, c, h, w)
+    Ym = Ys.reshape(B, *Ys.shape[-2:])
+    g = gate(gam_attention(Fm, Ym), p, gate_mask)
+    proto = masked_avg_pool_project(g * Fm, Ym, p)               # [B,c,1,1]
+    proto = proto.reshape(N, way, shot, c)
+    out = []
+    for n in range(N):
+        Wn = p["weight"].clone()
+        if weight_mask is not None:
+            Wn = Wn * weight_mask[n]
+        pbar = proto[n].mean(dim=1)                              # [way,c]
+        for j in range(way):                                     # later way wins
+            Wn[int(labels[n, j])] = pbar[j]
+        out.append(Wn)
+    return torch.stack(out, 0)
+
+
+# --------------------------------------------------------------------------
+# K3 / K3e: classifier and binary-logit extraction
+# --------------------------------------------------------------------------
+def classify(Fq, Wn):
+    """logits[n,k,y,x] = sum_c Fq[n,c,y,x]*Wn[n,k,c]  (model/common.py:390-394)."""
+    N, c, h, w = Fq.shape
+    x = Fq.permute(0, 2, 3, 1).reshape(N, h * w, c)
+    return torch.bmm(x, Wn.transpose(1, 2)).transpose(1, 2).reshape(N, -1, h, w)
+
+
+def binary_logits(logits_full, label, base=True):
+    """[N,K,h,w],[N] -> [N,2,h,w]; ch0 = max over the other K-1 rows (or row 0
+    when base=False), ch1 = row `label`  (utils/operations.py:313-338)."""
+    N, K = logits_full.shape[:2]
+    idx = torch.arange(N)
+    fg = logits_full[idx, label]
+    if base:
+        keep = torch.arange(K).unsqueeze(0) != label.unsqueeze(1)             # [N,K]
+        neg = torch.finfo(logits_full.dtype).min
+        bg = torch.where(keep[:, :, None, None], logits_full,
+                         torch.full_like(logits_full, neg)).max(dim=1)[0]
+    else:
+        bg = logits_full[:, 0]
+    return torch.stack([bg, fg], dim=1)
+
+
+def head_forward(Fq, Fs, Ys, label, p, gate_mask=None, weight_mask=None):
+    """DENet.forward after the feature producer (model/head/denet.py:57-93).
+    label is [N] (way==1) or [N,way]. Returns (logits_full, logits_binary, Wn)."""
+    way = Fs.shape[1]
+    lab = label.unsqueeze(-1) if label.dim() == 1 else label
+    Wn = extend_weights(Fs, Ys, lab, p, gate_mask, weight_mask)
+    full = classify(Fq, Wn)
+    if way > 1:
+        b = torch.stack([binary_logits(full, lab[:, i]) for i in range(way)], dim=1)
+        b = b.reshape(-1, *b.shape[2:])
+    else:
+        b = binary_logits(full, lab[:, 0])
+    return full, b, Wn
+
+
+# --------------------------------------------------------------------------
+# K4 / K5: upsample + losses
+# --------------------------------------------------------------------------
+def upsample(x, size):
+    return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=True)
+
+
+def weighted_ce_2d(up, target, weight=None):
+    """cross_entropy2d on already-upsampled logits (loss/losses.py:39-44)."""
+    K = up.shape[1]
+    x = up.permute(0, 2, 3, 1).reshape(-1, K)
+    return F.cross_entropy(x, target.reshape(-1), weight=weight, ignore_index=IGNORE)
+
+
+def loss_knowledge(full_up, Yq_full, wgt):
+    """mean over episodes of per-episode weighted CE (trainer/utils.py:270-277)."""
+    N = full_up.shape[0]
+    tot = 0.0
+    for n in range(N):
+        tot = tot + weighted_ce_2d(full_up[n:n + 1].float(), Yq_full[n:n + 1].long(), wgt[n])
+    return tot / N
+
+
+def loss_pattern(bin_up, Yq):
+    """binary focal loss, alpha .25 gamma 2 (loss/losses.py:47-79)."""
+    x = bin_up.float().permute(0, 2, 3, 1).reshape(-1, bin_up.shape[1])
+    t = Yq.long().reshape(-1)
+    prob = F.softmax(x, dim=-1)
+    foc = (1 - prob) ** FOCAL_GAMMA * torch.log(prob)
+    a = torch.tensor([FOCAL_ALPHA, 1 - FOCAL_ALPHA])
+    return F.nll_loss(foc, t, weight=a, ignore_index=IGNORE)
+
+
+def head_step(Fq, Fs, Ys, label, Yq, Yq_full, wgt, p, gate_mask=None, weight_mask=None,
+              backward=True):
+    """Everything the bench boundary covers: forward, both
+    losses, and loss_k.backward() (trainer/trainers.py:951-975).  Returns a
+    dict with logits, losses and, if backward, grads of Fq, Fs and params."""
+    Fq = Fq.detach().float().requires_grad_(backward)
+    Fs = Fs.detach().float().requires_grad_(backward)
+    pp = {k: v.detach().clone().requires_grad_(backward) for k, v in p.items()}
+    full, binl, Wn = head_forward(Fq, Fs, Ys, label, pp, gate_mask, weight_mask)
+    size = Yq_full.shape[-2:]
+    full_up = upsample(full, size)
+    bin_up = upsample(binl.float(), size)
+    lk = loss_knowledge(full_up, Yq_full, wgt)
+    lp = loss_pattern(bin_up, Yq.reshape(-1, *size))
+    out = dict(logits_full=full.detach(), logits_binary=binl.detach(), weights=Wn.detach(),
+               full_up=full_up.detach(), bin_up=bin_up.detach(),
+               loss_k=lk.detach(), loss_p=lp.detach())
+    if backward:
+        lk.backward()
+        out["dFq"] = Fq.grad
+        out["dFs"] = Fs.grad
+        for k, v in pp.items():
+            out["d:" + k] = v.grad
+    return out
+
+
+# --------------------------------------------------------------------------
+# M1 / M2: metrics (utils/metrics.py)
+# --------------------------------------------------------------------------
+def confusion_matrix(label_true: np.ndarray, pred: np.ndarray, K: int) -> np.ndarray:
+    """mat[t,p] += 1 for 0 <= t < K  (utils/metrics.py:59-67). int64 [K,K]."""
+    t = label_true.reshape(-1)
+    q = pred.reshape(-1)
+    ok = (t >= 0) & (t < K)
+    return np.bincount(K * t[ok].astype(np.int64) + q[ok], minlength=K * K).reshape(K, K)
+
+
+def full_iou_from_mat(mat: np.ndarray, eps=1e-8):
+    """(utils/metrics.py:69-76)"""
+    hist = mat.astype(float)
+    d = np.diag(hist)
+    den = np.clip(hist.sum(1) + hist.sum(0) - d, eps, np.inf)
+    iu = d / den
+    return float(np.nanmean(iu)), iu
+
+
+def binary_iou_counts(label_true: np.ndarray, pred: np.ndarray):
+    """Per sample (skip, inter, union) (utils/metrics.py:10-31).
+    label_true, pred: [N,H,W] ints."""
+    out = []
+    for t, q in zip(label_true, pred):
+        if t.sum() == 0:
+            out.append((True, 0, 0))
+            continue
+        s = t + q
+        out.append((False, int((s == 2).sum()), int(((s == 1) | (s == 2)).sum())))
+    return out
+
+
+class BinaryIOUOracle:
+    """dict-insertion-order accumulation (utils/metrics.py:4-50)."""
+
+    def __init__(self):
+        self.inter, self.union = {}, {}
+
+    def update(self, label_true, pred, cls_ids):
+        for (skip, i, u), c in zip(binary_iou_counts(label_true, pred), cls_ids):
+            if skip:
+                continue
+            c = int(c)
+            self.inter[c] = self.inter.get(c, 0.0) + float(i)
+            self.union[c] = self.union.get(c, 0.0) + float(u)
+
+    def mean_iou(self):
+        return float(np.mean([self.inter[c] / self.union[c] for c in self.inter]))
+
+    def mean_bf_iou(self):
+        return sum(self.inter.values()) / sum(self.union.values())
+
+
+def min_top2_margin(up: torch.Tensor) -> float:
+    """Smallest top-1/top-2 gap over all pixels (SURVEY.md §7 hard parts)."""
+    top = up.topk(2, dim=1)[0]
+    return float((top[:, 0] - top[:, 1]).min())

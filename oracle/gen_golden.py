@@ -1,0 +1,261 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box has
+neither the reference nor any need for this script):
+
+    python oracle/gen_golden.py
+
+Recipe: `utils`, `loss` import normally from /root/reference;
+`model/common.py` is loaded by file path because `model/__init__.py` pulls in
+torchvision, which this image lacks.  `np.float` (removed in numpy >= 1.24) is
+aliased to `float` for `BinaryIOU._update` (utils/metrics.py:12-13).
+
+Only DATA is written: inputs, parameters and the reference's outputs.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state, CONFIGS  # noqa: E402
+
+if not hasattr(np, "float"):
+    np.float = float                      # shim, see module docstring
+
+import utils.metrics as ref_metrics       # noqa: E402  (reference)
+import utils.operations as ref_ops        # noqa: E402  (reference)
+import loss.losses as ref_losses          # noqa: E402  (reference)
+
+_spec = importlib.util.spec_from_file_location("ref_common", os.path.join(REF, "model/common.py"))
+ref_common = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_common)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def build_estimator(K, c, state):
+    we = ref_common.WeightEstimator(num_classes=K, depth=c)
+    we.load_state_dict(state)
+    return we
+
+
+def ref_denet_tail(we, Fq, Fs, Ys, label):
+    """model/head/denet.py:57-93 with the feature producer removed: the only
+    lines of DENet.forward that touch the head (cannot import the class: it
+    needs torchvision + a pretrained download)."""
+    way = Fs.shape[1]
+    lab = label.unsqueeze(-1) if way == 1 else label
+    full = we(Fq, Fs, Ys, lab, mode="training")
+    if way > 1:
+        b = torch.stack([ref_ops.get_binary_logits(full, lab[:, i]) for i in range(way)], 1)
+        b = ref_ops.merge_first_k_dim(b, (0, 1))
+    else:
+        b = ref_ops.get_binary_logits(full, lab[:, 0], base=True)
+    return full, b
+
+
+def ref_losses_like_trainer(full, binl, Yq, Yq_full, wgt):
+    """trainer/trainers.py:954-956 + trainer/utils.py:264-281 (restated glue,
+    calling the reference's loss functions)."""
+    size = Yq_full.shape[-2:]
+    b_up = F.interpolate(binl.float(), size=size, mode="bilinear", align_corners=True)
+    f_up = F.interpolate(full, size=size, mode="bilinear", align_corners=True)
+    N = f_up.shape[0]
+    lk = 0.0
+    for pre, tar, w in zip(f_up.chunk(N, 0), Yq_full.chunk(N, 0), wgt):
+        lk = lk + ref_losses.loss_denet(pre, tar, weight=w, mode="knowledge")
+    lk = lk / N
+    lp = ref_losses.loss_denet(b_up, Yq.reshape(-1, *size), mode="pattern")
+    return f_up, b_up, lk, lp
+
+
+def capture_case(shape: EpisodeShape, train: bool, fname: str, seed_offset=0, planted=False):
+    ep = make_episodes(shape, seed_offset=seed_offset, planted=planted, ignore_rows=3)
+    state = make_estimator_state(shape.K, shape.c)
+    if planted:
+        state["weight"] = ep["signatures"].clone()
+    we = build_estimator(shape.K, shape.c, state)
+    we.train(train)
+    rec = {}
+    if train:
+        torch.manual_seed(99 + seed_offset)
+        wmasks = []
+
+        def hook_gate(mod, inp, out):
+            rec["gate_mask"] = torch.where(inp[0] != 0, out / inp[0], torch.zeros_like(out)).detach()
+
+        def hook_w(mod, inp, out):
+            wmasks.append(torch.where(inp[0] != 0, out / inp[0], torch.zeros_like(out)).detach())
+
+        we.gam.gate[3].register_forward_hook(hook_gate)
+        we.dropout.register_forward_hook(hook_w)
+    Fq = ep["Fq"].float().clone().requires_grad_(True)
+    Fs = ep["Fs"].float().clone().requires_grad_(True)
+    full, binl = ref_denet_tail(we, Fq, Fs, ep["Ys"], ep["label"])
+    f_up, b_up, lk, lp = ref_losses_like_trainer(full, binl, ep["Yq"], ep["Yq_full"], ep["wgt"])
+    lk.backward()
+    d = {("in:" + k): v.float().numpy() if v.is_floating_point() else v.numpy() for k, v in ep.items()}
+    d.update({("param:" + k): v.numpy() for k, v in state.items()})
+    d["shape"] = np.array([shape.N, shape.way, shape.shot, shape.K, shape.c, shape.h, shape.w,
+                           shape.H, shape.W], dtype=np.int64)
+    d["out:logits_full"] = full.detach().numpy()
+    d["out:logits_binary"] = binl.detach().numpy()
+    d["out:loss_k"] = lk.detach().numpy()
+    d["out:loss_p"] = lp.detach().numpy()
+    d["out:dFq"] = Fq.grad.numpy()
+    d["out:dFs"] = Fs.grad.numpy()
+    for k, v in we.named_parameters():
+        d["grad:" + k] = v.grad.numpy()
+    # K1 intermediates (att, pooled prototype before the linear layer) in eval
+    if not train:
+        with torch.no_grad():
+            B = shape.N * shape.way * shape.shot
+            Fm = ep["Fs"].float().reshape(B, shape.c, shape.h, shape.w)
+            Ym = ep["Ys"].reshape(B, shape.H, shape.W)
+            att = F.adaptive_avg_pool2d(ref_common.GAM.mask(Fm, Ym), (1, 1))
+            g = we.gam.gate(att)
+            proto = we.map(g * Fm, Ym)
+            lab = ep["label"].unsqueeze(-1) if shape.way == 1 else ep["label"]
+            d["out:att"] = att.reshape(B, shape.c).numpy()
+            d["out:gate"] = g.reshape(B, shape.c).numpy()
+            d["out:proto"] = proto.reshape(B, shape.c).numpy()
+            d["out:weights"] = we.extend(ep["Fs"].float(), ep["Ys"], lab).numpy()
+    else:
+        d["mask:gate"] = rec["gate_mask"].reshape(-1, shape.c).numpy()
+        d["mask:weight"] = torch.stack(wmasks, 0).numpy()
+    # metrics on the reference's own upsampled logits
+    fi = ref_metrics.FullIOU(num_classes=shape.K)
+    fi.update(ep["Yq_full"], f_up.detach())
+    d["out:confmat"] = fi.mat.astype(np.int64)
+    d["out:full_miou"] = np.float64(fi.mean_iou())
+    bi = ref_metrics.BinaryIOU()
+    if shape.way > 1:
+        bu = b_up.detach().reshape(shape.N, shape.way, *b_up.shape[-3:])
+        for i in range(shape.way):
+            bi.update(ep["Yq"][:, i], bu[:, i], ep["label"][:, i].numpy())
+    else:
+        bi.update(ep["Yq"], b_up.detach(), ep["label"].numpy())
+    keys = list(bi.inter.keys())
+    d["out:biou_keys"] = np.array(keys, dtype=np.int64)
+    d["out:biou_inter"] = np.array([bi.inter[k] for k in keys], dtype=np.float64)
+    d["out:biou_union"] = np.array([bi.union[k] for k in keys], dtype=np.float64)
+    d["out:biou_mean"] = np.float64(bi.mean_iou()) if keys else np.float64("nan")
+    d["out:pred_full"] = f_up.detach().argmax(1).numpy().astype(np.uint8)
+    d["out:pred_bin"] = b_up.detach().max(1)[1].numpy().astype(np.uint8)
+    top = f_up.detach().topk(2, dim=1)[0]
+    d["out:min_margin"] = np.float32((top[:, 0] - top[:, 1]).min())
+    np.savez_compressed(os.path.join(OUT, fname), **d)
+    print(fname, "loss_k=%.6f loss_p=%.6f margin=%.3g" % (float(lk), float(lp), float(d["out:min_margin"])))
+
+
+def capture_metrics():
+    """M1/M2 directly at the metric boundary (predictions in -> counts out)."""
+    g = torch.Generator().manual_seed(4321)
+    K, N, H, W = 7, 3, 19, 23
+    d = {}
+    fi = ref_metrics.FullIOU(num_classes=K)
+    bi = ref_metrics.BinaryIOU()
+    for u in range(3):
+        yt = torch.randint(0, K, (N, H, W), generator=g)
+        yt[:, :2] = 255
+        if u == 1:
+            yt[0, 5] = 254         # another out-of-range value, dropped by `< n`
+        lp = torch.randn(N, K, H, W, generator=g)
+        lp[:, 3] = lp[:, 2]        # exact ties: first index must win
+        fi.update(yt, lp)
+        yb = torch.randint(0, 2, (N, H, W), generator=g)
+        if u == 0:
+            yb[1] = 0              # skipped sample
+        lb = torch.randn(N, 2, H, W, generator=g)
+        lb[:, 1, :3] = lb[:, 0, :3]
+        cls = np.array([5, 2, 5]) if u != 2 else np.array([9, 2, 1])
+        bi.update(yb, lb, cls)
+        d[f"in:yt{u}"], d[f"in:lp{u}"] = yt.numpy(), lp.numpy()
+        d[f"in:yb{u}"], d[f"in:lb{u}"], d[f"in:cls{u}"] = yb.numpy(), lb.numpy(), cls
+    d["out:mat"] = fi.mat.astype(np.int64)
+    d["out:miou"] = np.float64(fi.mean_iou())
+    d["out:class_iou"] = np.array([fi.class_iou()[k] for k in range(K)])
+    d["out:sub_miou"] = np.float64(fi.mean_subclasses_iou([1, 3, 4]))
+    keys = list(bi.inter.keys())
+    d["out:biou_keys"] = np.array(keys, dtype=np.int64)
+    d["out:biou_inter"] = np.array([bi.inter[k] for k in keys])
+    d["out:biou_union"] = np.array([bi.union[k] for k in keys])
+    d["out:biou_mean"] = np.float64(bi.mean_iou())
+    d["out:biou_bf"] = np.float64(bi.mean_bf_iou())
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **d)
+    print("metrics.npz", d["out:miou"], d["out:biou_mean"])
+
+
+def capture_index_tables():
+    """ATen's own index rules, observed through F.interpolate."""
+    d = {}
+    for (H, h) in [(321, 41), (642, 81), (65, 9), (50, 7), (70, 9), (33, 33), (5, 9)]:
+        src = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1).expand(1, 1, H, 2)
+        near = F.interpolate(src, size=(h, 2), mode="nearest")[0, 0, :, 0]
+        d[f"nearest_{H}_{h}"] = near.numpy().astype(np.int64)
+        # bilinear h -> H: interpolate a ramp and a one-hot basis to read taps
+        eye = torch.eye(h).view(1, h, h, 1).expand(1, h, h, 2).contiguous()
+        up = F.interpolate(eye, size=(H, 2), mode="bilinear", align_corners=True)[0, :, :, 0]  # [h,H]
+        d[f"bilinear_{h}_{H}"] = up.numpy()
+    np.savez_compressed(os.path.join(OUT, "index_tables.npz"), **d)
+    print("index_tables.npz")
+
+
+def capture_fullsize_checksums():
+    """C2 at full size: outputs reduced to a few numbers + sampled entries."""
+    shape = CONFIGS["C2"]
+    ep = make_episodes(shape)
+    state = make_estimator_state(shape.K, shape.c)
+    we = build_estimator(shape.K, shape.c, state).eval()
+    Fq = ep["Fq"].clone().requires_grad_(True)
+    Fs = ep["Fs"].clone().requires_grad_(True)
+    full, binl = ref_denet_tail(we, Fq, Fs, ep["Ys"], ep["label"])
+    f_up, b_up, lk, lp = ref_losses_like_trainer(full, binl, ep["Yq"], ep["Yq_full"], ep["wgt"])
+    lk.backward()
+    g = torch.Generator().manual_seed(5)
+
+    def sample(t, n=4096):
+        flat = t.detach().reshape(-1)
+        idx = torch.randint(0, flat.numel(), (n,), generator=g)
+        return idx.numpy(), flat[idx].numpy()
+
+    d = {"out:loss_k": lk.detach().numpy(), "out:loss_p": lp.detach().numpy()}
+    for name, t in [("logits_full", full), ("logits_binary", binl), ("dFq", Fq.grad), ("dFs", Fs.grad)] + \
+                   [("grad:" + k, v.grad) for k, v in we.named_parameters()]:
+        i, v = sample(t)
+        d["idx:" + name], d["val:" + name] = i, v
+        d["sum:" + name] = np.float64(t.detach().double().sum())
+        d["abs:" + name] = np.float64(t.detach().double().abs().sum())
+    fi = ref_metrics.FullIOU(num_classes=shape.K)
+    fi.update(ep["Yq_full"], f_up.detach())
+    d["out:confmat"] = fi.mat.astype(np.int64)
+    top = f_up.detach().topk(2, dim=1)[0]
+    d["out:min_margin"] = np.float32((top[:, 0] - top[:, 1]).min())
+    np.savez_compressed(os.path.join(OUT, "c2_fullsize.npz"), **d)
+    print("c2_fullsize.npz loss_k=%.6f loss_p=%.6f" % (float(lk), float(lp)))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    s1 = EpisodeShape("g1", N=2, way=1, shot=5, K=21, c=64, h=9, w=9, H=65, W=65, config_index=101, lam=2.5)
+    s2 = EpisodeShape("g2", N=2, way=2, shot=3, K=9, c=64, h=7, w=9, H=50, W=70, config_index=102)
+    s3 = EpisodeShape("g3", N=3, way=1, shot=1, K=5, c=64, h=9, w=9, H=65, W=65, config_index=103)
+    capture_case(s1, train=False, fname="eval_1way_5shot.npz")
+    capture_case(s2, train=False, fname="eval_2way_3shot.npz")
+    capture_case(s3, train=False, fname="eval_1way_1shot.npz")
+    capture_case(s1, train=True, fname="train_1way_5shot.npz", seed_offset=1)
+    capture_case(s3, train=False, fname="planted_1way_1shot.npz", planted=True, seed_offset=2)
+    capture_metrics()
+    capture_index_tables()
+    capture_fullsize_checksums()

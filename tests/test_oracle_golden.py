@@ -1,0 +1,90 @@
+"""CPU: the oracle (oracle/denet_oracle.py) against the fixtures captured
+from the reference's own code (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denet_oracle as O
+from helpers import CASES, load_case, rel_err
+
+TOL = 1e-5    # fp32, same op order as the reference -> essentially identical
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_head_step_matches_reference(name):
+    z, d, ep, params, gm, wm = load_case(name)
+    gm4 = gm.reshape(-1, d["c"], 1, 1) if gm is not None else None
+    out = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"],
+                      params, gate_mask=gm4, weight_mask=wm)
+    assert rel_err(out["logits_full"], z["out:logits_full"]) < TOL
+    assert rel_err(out["logits_binary"], z["out:logits_binary"]) < TOL
+    assert rel_err(out["loss_k"], z["out:loss_k"]) < TOL
+    assert rel_err(out["loss_p"], z["out:loss_p"]) < TOL
+    assert rel_err(out["dFq"], z["out:dFq"]) < 1e-4
+    assert rel_err(out["dFs"], z["out:dFs"]) < 1e-4
+    for k in params:
+        assert rel_err(out["d:" + k], z["grad:" + k]) < 1e-4, k
+    if "out:weights" in z.files:
+        assert rel_err(out["weights"], z["out:weights"]) < TOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_metrics_on_reference_predictions(name):
+    z, d, ep, params, gm, wm = load_case(name)
+    mat = O.confusion_matrix(ep["Yq_full"].numpy(), z["out:pred_full"].astype(np.int64), d["K"])
+    assert np.array_equal(mat, z["out:confmat"])
+    miou, _ = O.full_iou_from_mat(mat)
+    assert miou == float(z["out:full_miou"])
+    bi = O.BinaryIOUOracle()
+    pb = z["out:pred_bin"].astype(np.int64)
+    if d["way"] > 1:
+        pb = pb.reshape(d["N"], d["way"], d["H"], d["W"])
+        for i in range(d["way"]):
+            bi.update(ep["Yq"][:, i].numpy(), pb[:, i], ep["label"][:, i].numpy())
+    else:
+        bi.update(ep["Yq"].numpy(), pb, ep["label"].numpy())
+    assert list(bi.inter.keys()) == list(z["out:biou_keys"])
+    assert np.array_equal(np.array(list(bi.inter.values())), z["out:biou_inter"])
+    assert np.array_equal(np.array(list(bi.union.values())), z["out:biou_union"])
+    assert bi.mean_iou() == float(z["out:biou_mean"])
+
+
+def test_metric_boundary_fixture(golden_dir):
+    z = np.load(golden_dir + "/metrics.npz")
+    K = z["out:mat"].shape[0]
+    mat = np.zeros((K, K), dtype=np.int64)
+    bi = O.BinaryIOUOracle()
+    for u in range(3):
+        pred = torch.from_numpy(z[f"in:lp{u}"]).argmax(1).numpy()
+        mat += O.confusion_matrix(z[f"in:yt{u}"], pred, K)
+        pb = torch.from_numpy(z[f"in:lb{u}"]).max(1)[1].numpy()
+        bi.update(z[f"in:yb{u}"], pb, z[f"in:cls{u}"])
+    assert np.array_equal(mat, z["out:mat"])
+    miou, iu = O.full_iou_from_mat(mat)
+    assert miou == float(z["out:miou"])
+    assert np.array_equal(iu, z["out:class_iou"])
+    assert list(bi.inter.keys()) == list(z["out:biou_keys"])
+    assert bi.mean_iou() == float(z["out:biou_mean"])
+    assert bi.mean_bf_iou() == float(z["out:biou_bf"])
+
+
+def test_index_rules(golden_dir):
+    z = np.load(golden_dir + "/index_tables.npz")
+    for key in z.files:
+        kind, a, b = key.split("_")
+        a, b = int(a), int(b)
+        if kind == "nearest":                       # a = in (H), b = out (h)
+            assert np.array_equal(O.nearest_src_index(b, a), z[key]), key
+        else:                                       # bilinear a = in (h) -> b = out (H)
+            i0, i1, fr = O.bilinear_taps(b, a)
+            M = np.zeros((a, b), dtype=np.float32)
+            for q in range(b):
+                M[i0[q], q] += np.float32(1) - fr[q]
+                M[i1[q], q] += fr[q]
+            assert np.abs(M - z[key]).max() < 1e-6, key
+    assert list(O.nearest_src_index(41, 321)[:6]) == [0, 7, 15, 23, 31, 39]
+
+
+def test_planted_margin_is_wide(golden_dir):
+    z = np.load(golden_dir + "/planted_1way_1shot.npz")
+    assert float(z["out:min_margin"]) > 1e-4
