@@ -1,0 +1,126 @@
+"""ctypes binding of libdenet_hip.so (the C ABI declared in include/denet_hip.h).
+
+There is no CPU fallback: if the library is missing this module raises at
+import of the first op, and every op raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdenet_hip.so")
+
+F32, BF16 = 0, 1
+
+# signature table: p = device pointer (tensor / None), l = int64, i = int, f = float
+# the trailing stream argument is appended automatically ("s").
+_SIGS = {
+    "denet_mask_resize": "plllllpp",
+    "denet_masked_sum_fwd": "piplllp",
+    "denet_masked_sum_bwd": "pplllpi",
+    "denet_proto_extend_fwd": "pppppppppppp" "llllll" "pppp",
+    "denet_proto_extend_bwd": "pl" "ppppp" "ppp" "ppp" "llllll" "pppppppp" "pl",
+    "denet_classify_fwd": "pipp" "lllll" "i" "pp",
+    "denet_classify_shared_fwd": "pip" "llll" "p",
+    "denet_classify_bwd": "pip" "pppp" "llll" "pp",
+    "denet_upsample_wce_fwd": "ppp" "llllll" "ppp",
+    "denet_upsample_focal_fwd": "pp" "lllll" "ff" "p",
+    "denet_loss_finalize": "pp" "lll" "i" "ppp",
+    "denet_combine_slabs": "pppp" "ll" "p",
+    "denet_upsample_bilinear": "p" "lllll" "p",
+    "denet_confmat": "pp" "lll" "p",
+    "denet_confmat_fused": "pp" "llllll" "p",
+    "denet_binary_iou_counts": "pp" "ll" "p",
+    "denet_binary_iou_counts_fused": "pp" "lllll" "p",
+    "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl",
+    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllll" "pp" "ppppppp" "pl",
+}
+_NOSTREAM = {
+    "denet_version": (ctypes.c_char_p, ""),
+    "denet_strerror": (ctypes.c_char_p, "i"),
+    "denet_proto_extend_bwd_workspace": (ctypes.c_int64, "ll"),
+    "denet_classify_bwd_parts": (ctypes.c_int64, "l"),
+    "denet_head_step_workspace": (ctypes.c_int64, "lllllll"),
+}
+_CT = {"p": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float}
+
+EXPORTS = sorted(list(_SIGS) + list(_NOSTREAM))
+
+_lib = None
+
+
+class DenetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for loading itself)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DenetHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C denet_amd/csrc`. denet_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_CT[c] for c in sig] + [ctypes.c_void_p]
+    for name, (res, sig) in _NOSTREAM.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = [_CT[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise DenetHipError("denet_amd ops need device tensors (got a CPU tensor); there is no CPU path")
+        if not x.is_contiguous():
+            raise DenetHipError("denet_amd ops need contiguous tensors")
+        return x.data_ptr()
+    return int(x)
+
+
+def strerror(code: int) -> str:
+    return load().denet_strerror(code).decode()
+
+
+def call(name: str, *args):
+    """Enqueue `name` on torch's current stream; raise on a non-zero code."""
+    lib = load()
+    sig = _SIGS[name]
+    if len(args) != len(sig):
+        raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
+    conv = []
+    for c, a in zip(sig, args):
+        if c == "p":
+            conv.append(_ptr(a))
+        elif c == "f":
+            conv.append(float(a))
+        else:
+            conv.append(int(a))
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = getattr(lib, name)(*conv, stream)
+    if rc != 0:
+        raise DenetHipError(f"{name} failed: {strerror(rc)} (code {rc})")
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*[int(a) for a in args]))
+
+
+def feat_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise DenetHipError(f"features must be float32 or bfloat16, got {t.dtype}")

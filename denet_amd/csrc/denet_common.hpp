@@ -1,0 +1,79 @@
+// Shared device helpers for the DENet head kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/denet_hip.h"
+
+#define DENET_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#define DENET_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return DENET_E_LAUNCH;          \
+    } while (0)
+
+// ---- index rules (must reproduce ATen bit for bit) -------------------------
+// F.interpolate(mode='nearest'): src = min(int(floorf(dst * (float(in)/out))), in-1)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+__host__ __device__ __forceinline__ float nearest_scale(int in_size, int out_size) {
+    return (float)in_size / (float)out_size;
+}
+// bilinear, align_corners=True: scale = float(in-1)/(out-1) (0 if out<=1);
+// src = scale*dst; i0 = int(src); i1 = i0 + (i0 < in-1); frac = src - i0
+__host__ __device__ __forceinline__ float bilinear_scale(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+}
+__device__ __forceinline__ void bilinear_tap(int dst, float scale, int in_size, int& i0, float& frac) {
+    float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    frac = src - (float)i0;
+}
+
+// ---- wave / block reductions -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// bf16 <-> f32
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) {
+    return __uint_as_float(((unsigned int)u) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    // round to nearest even; NaN stays NaN
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct FeatIO;
+template <> struct FeatIO<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct FeatIO<unsigned short> {
+    static __device__ __forceinline__ float load(const unsigned short* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_bf16(v); }
+};

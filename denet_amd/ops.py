@@ -1,0 +1,359 @@
+"""Host-side operators over the C ABI (include/denet_hip.h).
+
+Two layers:
+  * thin functional wrappers, one per kernel, that allocate outputs with torch
+    (device memory is torch's job here, nothing else) and enqueue on torch's
+    current stream;
+  * torch.autograd.Function classes that give the head, the losses and the
+    fused head step the reference's differentiable behaviour.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import call, feat_code, query
+
+IGNORE_INDEX = 255
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def _as_i64(t):
+    return t if t.dtype == torch.int64 else t.long()
+
+
+# --------------------------------------------------------------------------
+# K0 / K1
+# --------------------------------------------------------------------------
+def mask_resize(Ys: torch.Tensor, h: int, w: int):
+    """[B,H,W] int64 -> (mask [B,h*w] f32, cnt [B] f32).  model/common.py:189-190."""
+    Ys = _as_i64(Ys).contiguous()
+    B, H, W = Ys.shape
+    mask = _f32(B, h * w, device=Ys.device)
+    cnt = _f32(B, device=Ys.device)
+    call("denet_mask_resize", Ys, B, H, W, h, w, mask, cnt)
+    return mask, cnt
+
+
+def masked_sum(Fs: torch.Tensor, mask: torch.Tensor):
+    """Fs [B,C,h,w] (f32/bf16), mask [B,P] -> S [B,C] f32."""
+    Fs = Fs.contiguous()
+    B, C = Fs.shape[:2]
+    P = Fs.shape[2] * Fs.shape[3]
+    S = _f32(B, C, device=Fs.device)
+    call("denet_masked_sum_fwd", Fs, feat_code(Fs), mask, B, C, P, S)
+    return S
+
+
+def masked_sum_bwd(mask, coef, shape, dtype):
+    B, C, h, w = shape
+    dFs = torch.empty(B, C, h, w, dtype=dtype, device=mask.device)
+    call("denet_masked_sum_bwd", mask, coef, B, C, h * w, dFs, feat_code(dFs))
+    return dFs
+
+
+# --------------------------------------------------------------------------
+# K2
+# --------------------------------------------------------------------------
+def proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask=None, weight_mask=None):
+    """-> (Wn [N,K,C], saved (hidden, gate, pool))."""
+    W1, b1, W2, b2, Wl, bl, weight = params
+    C = S.shape[1]
+    dev = S.device
+    hidden, gate, pool = _f32(S.shape[0], C, device=dev), _f32(S.shape[0], C, device=dev), _f32(S.shape[0], C, device=dev)
+    Wn = _f32(N, K, C, device=dev)
+    call("denet_proto_extend_fwd", S, cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask,
+         N, way, shot, K, C, P, hidden, gate, pool, Wn)
+    return Wn, (hidden, gate, pool)
+
+
+def proto_extend_bwd(dWn_part, n_part, S, cnt, saved, params, labels, N, way, shot, K, P,
+                     gate_mask=None, weight_mask=None):
+    hidden, gate, pool = saved
+    W1, b1, W2, b2, Wl, bl, weight = params
+    C = S.shape[1]
+    B = S.shape[0]
+    dev = S.device
+    dW1, dW2, dWl = (torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wl))
+    db1, db2, dbl = (_f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev))
+    dweight = _f32(K, C, device=dev)
+    coef = _f32(B, C, device=dev)
+    nbytes = query("denet_proto_extend_bwd_workspace", B, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    call("denet_proto_extend_bwd", dWn_part, n_part, S, cnt, hidden, gate, pool, W1, W2, Wl, labels,
+         gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl, dweight, coef, ws, nbytes)
+    return dict(dW1=dW1, db1=db1, dW2=dW2, db2=db2, dWl=dWl, dbl=dbl, dweight=dweight, coef=coef)
+
+
+# --------------------------------------------------------------------------
+# K3
+# --------------------------------------------------------------------------
+def classify(Fq, Wn, labels=None, way=0, base=True):
+    """Fq [N,C,h,w], Wn [N,K,C] -> logits [N,K,h,w] (+ binary [N*way,2,h,w] if labels)."""
+    Fq = Fq.contiguous()
+    N, C, h, w = Fq.shape
+    K = Wn.shape[1]
+    logits = _f32(N, K, h, w, device=Fq.device)
+    binl = _f32(N * way, 2, h, w, device=Fq.device) if labels is not None else None
+    call("denet_classify_fwd", Fq, feat_code(Fq), Wn, labels, N, way, K, C, h * w, 1 if base else 0, logits, binl)
+    return logits, binl
+
+
+def classify_shared(Fq, W):
+    Fq = Fq.contiguous()
+    N, C, h, w = Fq.shape
+    K = W.shape[0]
+    logits = _f32(N, K, h, w, device=Fq.device)
+    call("denet_classify_shared_fwd", Fq, feat_code(Fq), W.contiguous(), N, K, C, h * w, logits)
+    return logits
+
+
+def classify_bwd(Fq, Wn, dlog_a, dlog_b=None, scale=None, gmul=None, need_dFq=True, need_dWn=True):
+    Fq = Fq.contiguous()
+    N, C, h, w = Fq.shape
+    K = Wn.shape[1]
+    P = h * w
+    n_part = query("denet_classify_bwd_parts", P)
+    dFq = torch.empty_like(Fq) if need_dFq else None
+    dWn_part = _f32(N, n_part, K, C, device=Fq.device) if need_dWn else None
+    call("denet_classify_bwd", Fq, feat_code(Fq), Wn, dlog_a, dlog_b, scale, gmul, N, K, C, P, dFq, dWn_part)
+    return dFq, dWn_part, n_part
+
+
+# --------------------------------------------------------------------------
+# K4 / K5
+# --------------------------------------------------------------------------
+def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False):
+    """-> (loss scalar tensor, per_episode [N], scale [N], dlog_a, dlog_b)."""
+    logits = logits.contiguous()
+    N, K, h, w = logits.shape
+    Y = _as_i64(Yq_full).contiguous().reshape(N, *Yq_full.shape[-2:])
+    H, W = Y.shape[-2:]
+    dev = logits.device
+    part = _f32(N, h, 2, device=dev)
+    da = torch.empty_like(logits) if grad else None
+    db = torch.empty_like(logits) if grad else None
+    call("denet_upsample_wce_fwd", logits, Y, wgt, N, K, h, w, H, W, part, da, db)
+    out = _f32(2, device=dev)
+    per = _f32(N, device=dev)
+    scale = _f32(N, device=dev)
+    call("denet_loss_finalize", part, None, N, 0, h, 1 if pooled else 0, out, per, scale)
+    return out[0], per, scale, da, db
+
+
+def upsample_focal(logits_binary, Yq, alpha=0.25, gamma=2.0):
+    lb = logits_binary.contiguous()
+    NB, two, h, w = lb.shape
+    assert two == 2
+    Y = _as_i64(Yq).contiguous().reshape(NB, *Yq.shape[-2:])
+    H, W = Y.shape[-2:]
+    part = _f32(NB, h, 2, device=lb.device)
+    call("denet_upsample_focal_fwd", lb, Y, NB, h, w, H, W, alpha, gamma, part)
+    out = _f32(2, device=lb.device)
+    call("denet_loss_finalize", None, part, 0, NB, h, 0, out, None, None)
+    return out[1]
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) for [N,C,h,w] f32."""
+    x = x.contiguous()
+    N, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    out = _f32(N, C, H, W, device=x.device)
+    step = 32768
+    xf, of = x.reshape(N * C, h, w), out.reshape(N * C, H, W)
+    for i in range(0, N * C, step):
+        call("denet_upsample_bilinear", xf[i:i + step], min(step, N * C - i), h, w, H, W, of[i:i + step])
+    return out
+
+
+def combine_slabs(a, b, scale, gmul):
+    N = a.shape[0]
+    out = torch.empty_like(a)
+    call("denet_combine_slabs", a, b, scale, gmul, N, a[0].numel(), out)
+    return out
+
+
+# --------------------------------------------------------------------------
+# metrics
+# --------------------------------------------------------------------------
+def confmat_update(mat, label_trues, preds):
+    """mat [K,K] int64 (device) += confusion counts.  preds [N,K,H,W] or low-res [N,K,h,w]."""
+    K = mat.shape[0]
+    yt = _as_i64(label_trues).contiguous()
+    preds = preds.float().contiguous()
+    N = preds.shape[0]
+    H, W = yt.shape[-2:]
+    if tuple(preds.shape[-2:]) == (H, W):
+        call("denet_confmat", preds, yt, N, K, H * W, mat)
+    else:
+        call("denet_confmat_fused", preds, yt, N, K, preds.shape[2], preds.shape[3], H, W, mat)
+    return mat
+
+
+def binary_counts(label_trues, preds2):
+    """-> int64 [N,3] = (sum true, inter, union).  preds2 [N,2,H,W] or low-res [N,2,h,w]."""
+    yt = _as_i64(label_trues).contiguous()
+    preds2 = preds2.float().contiguous()
+    N = preds2.shape[0]
+    H, W = yt.shape[-2:]
+    counts = torch.zeros(N, 3, dtype=torch.int64, device=preds2.device)
+    if tuple(preds2.shape[-2:]) == (H, W):
+        call("denet_binary_iou_counts", preds2, yt, N, H * W, counts)
+    else:
+        call("denet_binary_iou_counts_fused", preds2, yt, N, preds2.shape[2], preds2.shape[3], H, W, counts)
+    return counts
+
+
+# --------------------------------------------------------------------------
+# autograd: estimator (extend + infer), reference model/common.py:401-426
+# --------------------------------------------------------------------------
+class EstimatorFunction(torch.autograd.Function):
+    """(Fq, Fs, weight, W1, b1, W2, b2, Wl, bl | Ys, labels, masks) -> (logits_full, logits_binary, Wn).
+
+    logits_binary and Wn are returned non-differentiable: the reference only ever
+    back-propagates loss_k, which depends on logits_full (trainer/trainers.py:972-974).
+    """
+
+    @staticmethod
+    def forward(ctx, Fq, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, gate_mask, weight_mask, base):
+        N, way, shot, C, h, w = Fs.shape
+        K = weight.shape[0]
+        B, P = N * way * shot, h * w
+        Fs_m = Fs.contiguous().reshape(B, C, h, w)
+        mask, cnt = mask_resize(Ys.reshape(B, *Ys.shape[-2:]), h, w)
+        S = masked_sum(Fs_m, mask)
+        params = tuple(t.contiguous() for t in (W1, b1, W2, b2, Wl, bl, weight))
+        labels = _as_i64(labels).contiguous()
+        Wn, saved = proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask, weight_mask)
+        logits, binl = classify(Fq, Wn, labels, way, base)
+        ctx.save_for_backward(Fq, mask, cnt, S, Wn, labels, *saved, *params,
+                              *(t for t in (gate_mask, weight_mask) if t is not None))
+        ctx.has_masks = (gate_mask is not None, weight_mask is not None)
+        ctx.dims = (N, way, shot, K, C, h, w)
+        ctx.fs_dtype = Fs.dtype
+        ctx.mark_non_differentiable(binl, Wn)
+        ctx.set_materialize_grads(False)
+        return logits, binl, Wn
+
+    @staticmethod
+    def backward(ctx, dlogits, dbin, dWn_unused):
+        if dbin is not None:
+            raise NotImplementedError("gradient through logits_binary is not implemented "
+                                      "(the reference never back-propagates loss_p)")
+        N, way, shot, K, C, h, w = ctx.dims
+        sv = ctx.saved_tensors
+        Fq, mask, cnt, S, Wn, labels, hidden, gate, pool, W1, b1, W2, b2, Wl, bl, weight = sv[:16]
+        rest = list(sv[16:])
+        gate_mask = rest.pop(0) if ctx.has_masks[0] else None
+        weight_mask = rest.pop(0) if ctx.has_masks[1] else None
+        if dlogits is None:
+            return (None,) * 14
+        dFq, dWn_part, n_part = classify_bwd(Fq, Wn, dlogits.contiguous().float())
+        g = proto_extend_bwd(dWn_part, n_part, S, cnt, (hidden, gate, pool), (W1, b1, W2, b2, Wl, bl, weight),
+                             labels, N, way, shot, K, h * w, gate_mask, weight_mask)
+        dFs = masked_sum_bwd(mask, g["coef"], (N * way * shot, C, h, w), ctx.fs_dtype)
+        dFs = dFs.reshape(N, way, shot, C, h, w)
+        return (dFq, dFs, g["dweight"], g["dW1"], g["db1"], g["dW2"], g["db2"], g["dWl"], g["dbl"],
+                None, None, None, None, None)
+
+
+# --------------------------------------------------------------------------
+# autograd: losses on (possibly low-res) logits, reference loss/losses.py
+# --------------------------------------------------------------------------
+class UpsampleWCEFunction(torch.autograd.Function):
+    """cross_entropy2d with the bilinear up-sampling fused in (loss/losses.py:19-44).
+    pooled=True: one weighted mean over the batch; False: mean of per-sample means
+    (trainer/utils.py:270-277)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, wgt, pooled):
+        need = logits.requires_grad
+        loss, per, scale, da, db = upsample_wce(logits, target, wgt, grad=need, pooled=pooled)
+        if need:
+            ctx.save_for_backward(scale, da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        scale, da, db = ctx.saved_tensors
+        g = gout.contiguous().float().reshape(1)
+        return combine_slabs(da, db, scale, g), None, None, None
+
+
+class UpsampleFocalFunction(torch.autograd.Function):
+    """binary_focal_loss with the up-sampling fused in (loss/losses.py:47-79); forward only."""
+
+    @staticmethod
+    def forward(ctx, logits_binary, target, alpha, gamma):
+        return upsample_focal(logits_binary, target, alpha, gamma)
+
+    @staticmethod
+    def backward(ctx, gout):
+        raise NotImplementedError("binary_focal_loss backward is not implemented: the reference only "
+                                  "logs loss_p and never back-propagates it (trainer/trainers.py:972-974)")
+
+
+# --------------------------------------------------------------------------
+# autograd: the fused head step (T1)
+# --------------------------------------------------------------------------
+class HeadStepFunction(torch.autograd.Function):
+    """One call for forward + both losses; backward runs K3b/K2b/K1b from the
+    gradient slabs the forward already wrote.  Returns
+    (loss_k, loss_p, logits_full, logits_binary); only loss_k is differentiable."""
+
+    @staticmethod
+    def forward(ctx, Fq, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask):
+        N, way, shot, C, h, w = Fs.shape
+        K = weight.shape[0]
+        dev = Fq.device
+        Fq, Fs = Fq.contiguous(), Fs.contiguous()
+        params = tuple(t.contiguous() for t in (weight, W1, b1, W2, b2, Wl, bl))
+        labels = _as_i64(labels).contiguous()
+        Ys = _as_i64(Ys).contiguous()
+        H, W = Ys.shape[-2:]
+        Yq = _as_i64(Yq).contiguous() if Yq is not None else None
+        Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
+        need = any(t.requires_grad for t in (Fq, Fs) + params)
+        nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        logits = _f32(N, K, h, w, device=dev)
+        binl = _f32(N * way, 2, h, w, device=dev)
+        losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *params,
+             gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
+             ws, nbytes)
+        ctx.dims = (N, way, shot, K, C, h, w)
+        ctx.ws = ws
+        ctx.fs_shape = Fs.shape
+        ctx.save_for_backward(Fq, labels, params[1], params[3], params[5],
+                              *(t for t in (gate_mask, weight_mask) if t is not None))
+        ctx.has_masks = (gate_mask is not None, weight_mask is not None)
+        loss_k, loss_p = losses[0], losses[1]
+        ctx.mark_non_differentiable(loss_p, logits, binl)
+        ctx.set_materialize_grads(False)
+        return loss_k, loss_p, logits, binl
+
+    @staticmethod
+    def backward(ctx, g_k, g_p, g_l, g_b):
+        if g_k is None:
+            return (None,) * 16
+        N, way, shot, K, C, h, w = ctx.dims
+        sv = list(ctx.saved_tensors)
+        Fq, labels, W1, W2, Wl = sv[:5]
+        rest = sv[5:]
+        gate_mask = rest.pop(0) if ctx.has_masks[0] else None
+        weight_mask = rest.pop(0) if ctx.has_masks[1] else None
+        dev = Fq.device
+        dFq = torch.empty_like(Fq)
+        dFs = torch.empty(ctx.fs_shape, dtype=Fq.dtype, device=dev)
+        dweight = _f32(K, C, device=dev)
+        dW1, dW2, dWl = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wl)
+        db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
+        g = g_k.contiguous().float().reshape(1)
+        call("denet_head_step_bwd", Fq, feat_code(Fq), labels, W1, W2, Wl, gate_mask, weight_mask, g,
+             N, way, shot, K, C, h, w, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws, ctx.ws.numel())
+        return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7

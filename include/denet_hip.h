@@ -1,0 +1,219 @@
+/*
+ * denet_hip.h -- C ABI of libdenet_hip.so: the MI355X (gfx950) kernels behind
+ * the DENet few-shot segmentation head.
+ *
+ * The reference (lizhaoliu-Lec/DENet) is pure Python/PyTorch and has no FFI;
+ * every entry point below replaces a chain of stock ATen ops in the reference
+ * file:line it cites (paths relative to the reference root).  The host side
+ * (denet_amd/, Python) binds these with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers into caller-owned memory unless noted.
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as
+ *    void*); nothing here allocates, frees or synchronises.
+ *  - Return value: DENET_OK (0) or a negative DENET_E_* code; nothing throws.
+ *    denet_strerror() turns a code into text.
+ *  - Tensors are contiguous, row-major, in the layouts the reference uses:
+ *      features  NCHW        [B, C, h, w]   fp32 (DENET_F32) or bf16 (DENET_BF16)
+ *      masks     [B, H, W]   int64
+ *      logits    [N, K, h, w] fp32
+ *  - B = N*way*shot support images, P = h*w feature positions.
+ *  - C must be a multiple of 64 and <= 512; K <= 128.
+ */
+#ifndef DENET_HIP_H
+#define DENET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DENET_OK            0
+#define DENET_E_BADARG     -1   /* null pointer / non-positive dimension            */
+#define DENET_E_UNSUPPORTED -2  /* shape outside what the kernels were built for    */
+#define DENET_E_LAUNCH     -3   /* hipLaunchKernel reported an error                */
+#define DENET_E_WORKSPACE  -4   /* workspace too small                              */
+
+#define DENET_F32  0
+#define DENET_BF16 1
+
+/* Library version / build arch string ("gfx950"). Host pointers. */
+const char* denet_version(void);
+const char* denet_strerror(int code);
+
+/* ---- K1: masked pooling -------------------------------------------------
+ * Replaces GAM.mask + adaptive_avg_pool2d (model/common.py:234-243) and the
+ * pooling branch of MaskedAveragePooling.forward (model/common.py:188-194).
+ * One pass over Fs yields everything both need:
+ *   mask[b,p] = float(Ys[b, sy(p), sx(p)])     nearest: s = min(floor(d*fp32(in/out)), in-1)
+ *   cnt[b]    = sum_p mask[b,p]
+ *   S[b,c]    = sum_p mask[b,p] * Fs[b,c,p]
+ */
+int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_t W, int64_t h, int64_t w,
+                      float* mask /*[B,h*w]*/, float* cnt /*[B]*/, void* stream);
+int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float* mask, int64_t B, int64_t C,
+                         int64_t P, float* S /*[B,C]*/, void* stream);
+/* Backward of the above (autograd of model/common.py:192,239,243,245):
+ *   dFs[b,c,p] = mask[b,p] * coef[b,c]     (rank-1; Fs itself is not re-read) */
+int denet_masked_sum_bwd(const float* mask, const float* coef /*[B,C]*/, int64_t B, int64_t C,
+                         int64_t P, void* dFs, int feat_dtype, void* stream);
+
+/* ---- K2: gate, projection, dynamic extension ----------------------------
+ * Replaces GAM.gate (model/common.py:225-232,244), MaskedAveragePooling's
+ * division + 1x1 conv (model/common.py:194-196), WeightEstimator._extend
+ * (model/common.py:317-339) and the per-episode Python loop (:368).
+ *   att = S/P; hidden = relu(W1 att + b1); z = W2 hidden + b2
+ *   g = sigmoid(z * gate_mask); pool = g*S/(cnt+1e-3); proto = Wl pool + bl
+ *   Wn[n] = weight * weight_mask[n]; Wn[n, labels[n,j]] = mean_s proto[n,j,s]
+ *           (j ascending: a later way wins a duplicated label)
+ * labels are read ON DEVICE (no .item() sync, cf. model/common.py:328).
+ * gate_mask [B,C] / weight_mask [N,K,C]: already-scaled dropout multipliers
+ * (0 or 1/(1-p)) or NULL for eval mode.
+ * hidden, gate, pool [B,C] are saved for the backward pass.
+ */
+int denet_proto_extend_fwd(const float* S, const float* cnt,
+                           const float* W1, const float* b1, const float* W2, const float* b2,
+                           const float* Wl, const float* bl, const float* weight,
+                           const int64_t* labels /*[N,way]*/,
+                           const float* gate_mask, const float* weight_mask,
+                           int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P,
+                           float* hidden, float* gate, float* pool, float* Wn /*[N,K,C]*/,
+                           void* stream);
+
+/* Backward of K2 (autograd of the same lines).  Inputs: dWn [N,K,C] given as
+ * `n_part` partial slabs [N,n_part,K,C] that are summed here (K3b writes one
+ * slab per position tile).  Outputs: gradients of the seven parameters and
+ * coef [B,C] for denet_masked_sum_bwd.  ws: workspace of
+ * denet_proto_extend_bwd_workspace(B,C) bytes. */
+int64_t denet_proto_extend_bwd_workspace(int64_t B, int64_t C);
+int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part,
+                           const float* S, const float* cnt,
+                           const float* hidden, const float* gate, const float* pool,
+                           const float* W1, const float* W2, const float* Wl,
+                           const int64_t* labels, const float* gate_mask, const float* weight_mask,
+                           int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P,
+                           float* dW1, float* db1, float* dW2, float* db2, float* dWl, float* dbl,
+                           float* dweight /*[K,C]*/, float* coef /*[B,C]*/,
+                           void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- K3: per-pixel classifier (MFMA) + binary-logit extraction ----------
+ * Replaces WeightEstimator.infer, training branch (model/common.py:390-394):
+ *   logits[n,k,p] = sum_c Fq[n,c,p] * Wn[n,k,c]          (plain dot product)
+ * and get_binary_logits(base=True) (utils/operations.py:313-338) per way:
+ *   bin[n*way+j, 1, p] = logits[n, labels[n,j], p]
+ *   bin[n*way+j, 0, p] = max_{k != labels[n,j]} logits[n,k,p]
+ * logits_binary may be NULL.  base=0 selects the base=False variant (row 0 as
+ * background, utils/operations.py:334-336).
+ */
+int denet_classify_fwd(const void* Fq, int feat_dtype, const float* Wn, const int64_t* labels,
+                       int64_t N, int64_t way, int64_t K, int64_t C, int64_t P, int base,
+                       float* logits /*[N,K,P]*/, float* logits_binary /*[N*way,2,P]*/,
+                       void* stream);
+/* Shared-matrix variant for mode='deploy' (model/common.py:395-399): Wn is
+ * [K,C] and used for every n. */
+int denet_classify_shared_fwd(const void* Fq, int feat_dtype, const float* W,
+                              int64_t N, int64_t K, int64_t C, int64_t P,
+                              float* logits, void* stream);
+
+/* Backward of K3 (autograd of model/common.py:392-393):
+ *   dL = scale[n] * (dlog_a + dlog_b)     (the two slabs K4 writes; dlog_b may be NULL,
+ *                                          scale may be NULL = 1)
+ *   dFq[n,c,p]  = sum_k Wn[n,k,c] * dL[n,k,p]
+ *   dWn_part[n,t,k,c] = sum_{p in tile t} dL[n,k,p] * Fq[n,c,p]
+ * n_part = denet_classify_bwd_parts(P) tiles. */
+int64_t denet_classify_bwd_parts(int64_t P);
+int denet_classify_bwd(const void* Fq, int feat_dtype, const float* Wn,
+                       const float* dlog_a, const float* dlog_b, const float* scale,
+                       const float* gmul /* device scalar multiplied into dL, or NULL */,
+                       int64_t N, int64_t K, int64_t C, int64_t P,
+                       void* dFq /* may be NULL */, float* dWn_part /* may be NULL */, void* stream);
+
+/* ---- K4/K5: fused bilinear up-sampling + losses --------------------------
+ * Replaces F.interpolate(bilinear, align_corners=True) of both logit tensors
+ * (trainer/trainers.py:954-956), the per-episode weighted cross entropy
+ * (trainer/utils.py:270-277 -> loss/losses.py:19-44) and the binary focal loss
+ * (loss/losses.py:47-79) without materialising the [N,K,H,W] tensor.
+ *   up = bilinear(logits), src = dst*(in-1)/(out-1)
+ *   num[n] = sum_q v*wgt[n,y]*(-log softmax(up)[y]);  den[n] = sum_q v*wgt[n,y]
+ *   v = (y != 255)
+ * With dlog_a/dlog_b non-NULL it also writes the UNSCALED gradient of
+ * sum_n num[n] w.r.t. the low-res logits as two slabs (rows touched as the
+ * upper / the lower bilinear tap), to be combined as scale[n]*(a+b) with
+ * scale[n] = 1/(N*den[n])  (loss_k is a mean over episodes of per-episode
+ * weighted means).
+ * Focal part (optional, logits_binary != NULL): Yq [NB,H,W], NB = N*way.
+ * part: workspace [N*h + NB*h, 4] floats of per-band partial sums.
+ * denet_loss_finalize reduces them: out[0]=loss_k, out[1]=loss_p.
+ *   pooled = 0: loss_k = mean_n num[n]/den[n], scale[n] = 1/(N*den[n])   (trainer/utils.py:270-277)
+ *   pooled = 1: loss_k = sum num / sum den,    scale[n] = 1/sum den      (loss/losses.py:39-44 on a batch)
+ * denet_combine_slabs: out = gmul * scale[n] * (a + b): the dense gradient
+ * w.r.t. the logits for callers that need it as a tensor.
+ */
+int denet_upsample_wce_fwd(const float* logits, const int64_t* Yq_full, const float* wgt /*[N,K] or NULL*/,
+                           int64_t N, int64_t K, int64_t h, int64_t w, int64_t H, int64_t W,
+                           float* part /*[N,h,2]*/, float* dlog_a, float* dlog_b, void* stream);
+int denet_upsample_focal_fwd(const float* logits_binary, const int64_t* Yq,
+                             int64_t NB, int64_t h, int64_t w, int64_t H, int64_t W,
+                             float alpha, float gamma, float* part /*[NB,h,2]*/, void* stream);
+int denet_loss_finalize(const float* part_k, const float* part_p, int64_t N, int64_t NB, int64_t h,
+                        int pooled, float* out /*[2]*/, float* per_episode /*[N] or NULL*/,
+                        float* scale /*[N] or NULL*/, void* stream);
+int denet_combine_slabs(const float* a, const float* b /*or NULL*/, const float* scale /*[N] or NULL*/,
+                        const float* gmul /*device scalar or NULL*/, int64_t N, int64_t per /*K*h*w*/,
+                        float* out, void* stream);
+/* Plain up-sampling for callers that need the tensor (DENetTrainer.step returns
+ * it, trainer/trainers.py:1003-1005). */
+int denet_upsample_bilinear(const float* x, int64_t NC, int64_t h, int64_t w, int64_t H, int64_t W,
+                            float* out /*[NC,H,W]*/, void* stream);
+
+/* ---- M1/M2: metrics -------------------------------------------------------
+ * FullIOU.update (utils/metrics.py:59-67): mat[t,argmax_k pred] += 1 for
+ * 0 <= t < K.  mat is int64 [K,K], accumulated in place (exact integer
+ * counts; first index wins ties like torch.argmax).
+ *   _confmat       : API-level, preds already up-sampled [N,K,H,W]
+ *   _confmat_fused : from low-res logits [N,K,h,w], up-sampling on the fly
+ * BinaryIOU.update (utils/metrics.py:24-31): per sample
+ *   counts[i] = {sum(true), #(true+pred==2), #(true+pred in {1,2})} int64
+ * (the host applies the skip rule and the per-class dictionaries). */
+int denet_confmat(const float* preds, const int64_t* label_true, int64_t N, int64_t K, int64_t HW,
+                  int64_t* mat, void* stream);
+int denet_confmat_fused(const float* logits, const int64_t* label_true, int64_t N, int64_t K,
+                        int64_t h, int64_t w, int64_t H, int64_t W, int64_t* mat, void* stream);
+int denet_binary_iou_counts(const float* preds2 /*[N,2,HW]*/, const int64_t* label_true,
+                            int64_t N, int64_t HW, int64_t* counts /*[N,3]*/, void* stream);
+int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int64_t* label_true,
+                                  int64_t N, int64_t h, int64_t w, int64_t H, int64_t W,
+                                  int64_t* counts /*[N,3]*/, void* stream);
+
+/* ---- T1: the whole head step as two enqueue-only calls -----------------------
+ * Everything DENetTrainer.step does between the feature producer and
+ * optimizer.step() (trainer/trainers.py:951-975; wrappers trainer/utils.py:
+ * 251-303): K0..K5 forward (+ the loss gradient slabs when with_grad), then
+ * K3b, K2b, K1b.  ws: denet_head_step_workspace(...) bytes, 256-B aligned,
+ * shared by the two calls of one step.  Yq / Yq_full may be NULL (test mode:
+ * no loss, trainer/trainers.py:958).  losses = {loss_k, loss_p} on device.
+ * grad_loss_k: device scalar d(objective)/d(loss_k), NULL = 1.  Only loss_k is
+ * back-propagated (trainer/trainers.py:972-974). */
+int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
+                                  int64_t h, int64_t w);
+int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
+                        const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
+                        const float* wgt, const float* weight, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const float* Wl, const float* bl,
+                        const float* gate_mask, const float* weight_mask,
+                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
+                        int64_t h, int64_t w, int64_t H, int64_t W, int with_grad,
+                        float* logits_full, float* logits_binary, float* losses,
+                        void* ws, int64_t ws_bytes, void* stream);
+int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
+                        const float* W1, const float* W2, const float* Wl,
+                        const float* gate_mask, const float* weight_mask, const float* grad_loss_k,
+                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                        void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
+                        float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENET_HIP_H */

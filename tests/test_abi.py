@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/denet_hip.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "denet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(denet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from denet_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/denet_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_version_and_strerror():
+    from denet_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.denet_version()
+    assert _lib.strerror(0) == "ok"
+    assert "workspace" in _lib.strerror(-4)
+
+
+def test_workspace_queries_are_pure_host_calls():
+    from denet_amd import _lib
+    assert _lib.query("denet_classify_bwd_parts", 1681) == 27
+    assert _lib.query("denet_proto_extend_bwd_workspace", 40, 256) == 3 * 40 * 256 * 4
+    assert _lib.query("denet_head_step_workspace", 8, 1, 5, 21, 256, 41, 41) > 0
+    assert _lib.query("denet_head_step_workspace", 0, 1, 5, 21, 256, 41, 41) < 0
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    import torch
+    from denet_amd import ops, _lib
+    with pytest.raises(_lib.DenetHipError):
+        ops.mask_resize(torch.zeros(1, 4, 4, dtype=torch.int64), 2, 2)

@@ -1,0 +1,183 @@
+"""GPU parity, kernel by kernel, through the C ABI (denet_amd.ops -> libdenet_hip.so)
+against the CPU oracle and the golden fixtures captured from the reference.
+
+Tolerances: fp32 logits / losses / gradients within 1e-3 relative
+(BASELINE.json north_star); in practice they agree to ~1e-6.  Integer work
+(mask resize, confusion matrices, IoU counts) is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _params(params, dev):
+    order = ["gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias", "weight"]
+    return tuple(params[k].to(dev).contiguous() for k in order)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_stages(name, dev):
+    from denet_amd import ops
+    from oracle import denet_oracle as O
+    z, d, ep, params, gm, wm = load_case(name)
+    N, way, shot, K, c, h, w, H, W = (d[k] for k in ("N", "way", "shot", "K", "c", "h", "w", "H", "W"))
+    B, P = N * way * shot, h * w
+    Fs = ep["Fs"].float().reshape(B, c, h, w)
+    Ys = ep["Ys"].reshape(B, H, W)
+    # --- K0: mask resize, bit exact vs ATen nearest
+    mask, cnt = ops.mask_resize(Ys.to(dev), h, w)
+    m_ref = O.resize_mask(Ys, h, w).reshape(B, P)
+    assert torch.equal(mask.cpu(), m_ref)
+    assert torch.equal(cnt.cpu(), m_ref.sum(1))
+    # --- K1
+    S = ops.masked_sum(Fs.to(dev), mask)
+    S_ref = (m_ref.unsqueeze(1) * Fs.reshape(B, c, P)).sum(-1)
+    assert rel_err(S.cpu(), S_ref) < TIGHT
+    if "out:att" in z.files:
+        assert rel_err(S.cpu() / P, z["out:att"]) < TIGHT
+    # --- K2
+    lab = ep["label"].reshape(N, way).to(dev)
+    gmd = gm.to(dev) if gm is not None else None
+    wmd = wm.to(dev).contiguous() if wm is not None else None
+    Wn, saved = ops.proto_extend(S, cnt, _params(params, dev), lab, N, way, shot, K, P, gmd, wmd)
+    if "out:gate" in z.files:
+        assert rel_err(saved[1].cpu(), z["out:gate"]) < TIGHT
+    Wn_ref = O.extend_weights(ep["Fs"].float(), ep["Ys"], ep["label"].reshape(N, way), params,
+                              gm.reshape(B, c, 1, 1) if gm is not None else None, wm)
+    assert rel_err(Wn.cpu(), Wn_ref) < TIGHT
+    if "out:weights" in z.files:
+        assert rel_err(Wn.cpu(), z["out:weights"]) < TIGHT
+    # --- K3 + K3e
+    logits, binl = ops.classify(ep["Fq"].float().to(dev), Wn, lab, way)
+    assert rel_err(logits.cpu(), z["out:logits_full"]) < TIGHT
+    assert rel_err(binl.cpu(), z["out:logits_binary"]) < TIGHT
+    # --- K4 / K5
+    loss_k, per, scale, _, _ = ops.upsample_wce(logits, ep["Yq_full"].to(dev), ep["wgt"].to(dev).contiguous())
+    assert rel_err(loss_k.cpu(), z["out:loss_k"]) < 1e-4
+    loss_p = ops.upsample_focal(binl, ep["Yq"].to(dev))
+    assert rel_err(loss_p.cpu(), z["out:loss_p"]) < 1e-4
+    # --- plain up-sampling vs ATen
+    up = ops.upsample_bilinear(logits, (H, W))
+    up_ref = O.upsample(torch.from_numpy(z["out:logits_full"]), (H, W))
+    assert rel_err(up.cpu(), up_ref) < TIGHT
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_backward_chain(name, dev):
+    from denet_amd import ops
+    z, d, ep, params, gm, wm = load_case(name)
+    N, way, shot, K, c, h, w, H, W = (d[k] for k in ("N", "way", "shot", "K", "c", "h", "w", "H", "W"))
+    order = ["gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias", "weight"]
+    P_ = {k: params[k].to(dev).contiguous().requires_grad_(True) for k in order}
+    Fq = ep["Fq"].float().to(dev).requires_grad_(True)
+    Fs = ep["Fs"].float().to(dev).requires_grad_(True)
+    gmd = gm.to(dev) if gm is not None else None
+    wmd = wm.to(dev).contiguous() if wm is not None else None
+    lab = ep["label"].reshape(N, way).to(dev)
+    logits, binl, Wn = ops.EstimatorFunction.apply(
+        Fq, Fs, P_["weight"], P_["gam.gate.0.weight"], P_["gam.gate.0.bias"], P_["gam.gate.2.weight"],
+        P_["gam.gate.2.bias"], P_["map.linear.weight"], P_["map.linear.bias"], ep["Ys"].to(dev), lab, gmd, wmd, True)
+    loss = ops.UpsampleWCEFunction.apply(logits, ep["Yq_full"].to(dev), ep["wgt"].to(dev).contiguous(), False)
+    loss.backward()
+    assert rel_err(loss.detach().cpu(), z["out:loss_k"]) < 1e-4
+    assert rel_err(Fq.grad.cpu(), z["out:dFq"]) < TOL
+    assert rel_err(Fs.grad.cpu(), z["out:dFs"]) < TOL
+    for k in order:
+        assert rel_err(P_[k].grad.cpu(), z["grad:" + k]) < TOL, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fused_head_step(name, dev):
+    from denet_amd import ops
+    z, d, ep, params, gm, wm = load_case(name)
+    N, way = d["N"], d["way"]
+    order = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias"]
+    P_ = [params[k].to(dev).contiguous().requires_grad_(True) for k in order]
+    Fq = ep["Fq"].float().to(dev).requires_grad_(True)
+    Fs = ep["Fs"].float().to(dev).requires_grad_(True)
+    gmd = gm.to(dev) if gm is not None else None
+    wmd = wm.to(dev).contiguous() if wm is not None else None
+    lab = ep["label"].reshape(N, way).to(dev)
+    lk, lp, logits, binl = ops.HeadStepFunction.apply(
+        Fq, Fs, *P_, ep["Ys"].to(dev), lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev),
+        ep["wgt"].to(dev).contiguous(), gmd, wmd)
+    lk.backward()
+    assert rel_err(logits.cpu(), z["out:logits_full"]) < TIGHT
+    assert rel_err(binl.cpu(), z["out:logits_binary"]) < TIGHT
+    assert rel_err(lk.detach().cpu(), z["out:loss_k"]) < 1e-4
+    assert rel_err(lp.cpu(), z["out:loss_p"]) < 1e-4
+    assert rel_err(Fq.grad.cpu(), z["out:dFq"]) < TOL
+    assert rel_err(Fs.grad.cpu(), z["out:dFs"]) < TOL
+    for k, t in zip(order, P_):
+        assert rel_err(t.grad.cpu(), z["grad:" + k]) < TOL, k
+
+
+def test_metrics_boundary_bit_exact(dev, golden_dir):
+    """Predictions in -> counts out, against the reference's own FullIOU/BinaryIOU."""
+    from denet_amd import ops
+    z = np.load(golden_dir + "/metrics.npz")
+    K = z["out:mat"].shape[0]
+    mat = torch.zeros(K, K, dtype=torch.int64, device=dev)
+    inter, union, order = {}, {}, []
+    for u in range(3):
+        ops.confmat_update(mat, torch.from_numpy(z[f"in:yt{u}"]).to(dev), torch.from_numpy(z[f"in:lp{u}"]).to(dev))
+        cnt = ops.binary_counts(torch.from_numpy(z[f"in:yb{u}"]).to(dev), torch.from_numpy(z[f"in:lb{u}"]).to(dev)).cpu()
+        for (st, i, un), c in zip(cnt.tolist(), z[f"in:cls{u}"].tolist()):
+            if st == 0:
+                continue
+            if c not in inter:
+                order.append(c)
+            inter[c] = inter.get(c, 0) + i
+            union[c] = union.get(c, 0) + un
+    assert np.array_equal(mat.cpu().numpy(), z["out:mat"])
+    assert order == list(z["out:biou_keys"])
+    assert [float(inter[c]) for c in order] == list(z["out:biou_inter"])
+    assert [float(union[c]) for c in order] == list(z["out:biou_union"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_metrics_on_upsampled_logits(name, dev):
+    """API-level metric kernels on the reference's own up-sampled logits are bit exact."""
+    from denet_amd import ops
+    from oracle import denet_oracle as O
+    z, d, ep, params, gm, wm = load_case(name)
+    K, H, W = d["K"], d["H"], d["W"]
+    f_up = O.upsample(torch.from_numpy(z["out:logits_full"]), (H, W))
+    mat = torch.zeros(K, K, dtype=torch.int64, device=dev)
+    ops.confmat_update(mat, ep["Yq_full"].to(dev), f_up.to(dev))
+    assert np.array_equal(mat.cpu().numpy(), z["out:confmat"])
+    b_up = O.upsample(torch.from_numpy(z["out:logits_binary"]), (H, W))
+    cnt = ops.binary_counts(ep["Yq"].reshape(-1, H, W).to(dev), b_up.to(dev)).cpu().numpy()
+    ref = O.binary_iou_counts(ep["Yq"].reshape(-1, H, W).numpy(), b_up.max(1)[1].numpy())
+    for (st, i, u), (skip, ri, ru) in zip(cnt.tolist(), ref):
+        assert (st == 0) == skip
+        if not skip:
+            assert (i, u) == (ri, ru)
+
+
+def test_fused_confmat_planted_margin(dev, golden_dir):
+    """End-to-end bit-exact confusion matrix from low-res logits, on the planted-margin
+    episode (min top-2 margin asserted >> fp32 noise)."""
+    from denet_amd import ops
+    z, d, ep, params, gm, wm = load_case("planted_1way_1shot")
+    assert float(z["out:min_margin"]) > 1e-4
+    K = d["K"]
+    mat = torch.zeros(K, K, dtype=torch.int64, device=dev)
+    ops.confmat_update(mat, ep["Yq_full"].to(dev), torch.from_numpy(z["out:logits_full"]).to(dev))
+    assert np.array_equal(mat.cpu().numpy(), z["out:confmat"])
