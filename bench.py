@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DENet head episodes/s, fwd+bwd, 1-way 5-shot (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the head over one batch of synthetic episodes already
+resident in HBM: K0..K5 forward, both losses, and the backward of loss_k down
+to dFq, dFs and the seven estimator parameter gradients (SURVEY.md §8d
+"boundary being timed").  Feature producer and optimizer are excluded, as in
+the metric's definition.  With N > 1 each rank owns its own batch (episodes are
+independent: weak scaling) and the step ends with ONE RCCL all-reduce (AVG) of
+the flat parameter-gradient bucket.
+
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel, timed with
+HIP events on the launch stream inside the timed region; `cpu_baseline` is the
+oracle (CPU restatement of the reference head, stock PyTorch CPU ops) on the
+same batch, on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from denet_amd import _lib                                    # noqa: E402
+from denet_amd.engine import HeadStepEngine, PARAM_ORDER      # noqa: E402
+from denet_amd.hiprt import Event                             # noqa: E402
+from denet_amd.synthetic import CONFIGS, EpisodeShape, make_episodes, make_estimator_state  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_bytes(s: EpisodeShape, sF: int):
+    """Algorithmic bytes per launch of each kernel of the step."""
+    N, way, shot, K, C = s.N, s.way, s.shot, s.K, s.c
+    B, P, Q, NB = N * way * shot, s.h * s.w, s.H * s.W, N * way
+    n_part = (P + 63) // 64
+    return {
+        "mask_resize": B * P * 8 + B * P * 4,
+        "masked_sum_fwd": B * C * P * sF + B * P * 4 + B * C * 4,
+        "proto_extend_fwd": 3 * C * C * 4 + K * C * 4 + N * K * C * 4 + 4 * B * C * 4,
+        "classify_fwd": N * C * P * sF + N * K * C * 4 + N * K * P * 4 + NB * 2 * P * 4,
+        "wce_fwd": N * Q * 8 + N * K * P * 4 + 2 * N * K * P * 4,
+        "focal_fwd": NB * Q * 8 + NB * 2 * P * 4,
+        "loss_finalize": (N + NB) * s.h * 8,
+        "classify_bwd": 2 * N * C * P * sF + 2 * N * K * P * 4 + N * K * C * 4 + N * n_part * K * C * 4,
+        "proto_extend_bwd": N * n_part * K * C * 4 * 2 + 3 * C * C * 4 * 2 + 8 * B * C * 4,
+        "masked_sum_bwd": B * C * P * sF + B * P * 4 + B * C * 4,
+    }
+
+
+def step_bytes_per_episode(s: EpisodeShape, sF: int) -> float:
+    """SURVEY.md §8d formula (compulsory traffic per episode, fwd + bwd, with loss_p)."""
+    w_, sh, K, C = s.way, s.shot, s.K, s.c
+    P, Q = s.h * s.w, s.H * s.W
+    fwd = w_ * sh * C * P * sF + w_ * sh * P * 8 + C * P * sF + K * P * 4 + 2 * w_ * P * 4 + Q * 8 + w_ * Q * 8
+    bwd = Q * 8 + K * P * 4 + 2 * K * P * 4 + 2 * C * P * sF + w_ * sh * C * P * sF + w_ * sh * P * 8
+    return float(fwd + bwd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default: the config's batch)")
+    ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured HIP graph")
+    ap.add_argument("--probe", default="auto", help="kernel to time with HIP events (name | auto | none)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", type=int, default=1, help="also report every kernel's duration (untimed pass)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    shape = CONFIGS[args.config]
+    if args.episodes > 0:
+        shape = EpisodeShape(**{**shape.asdict(), "N": args.episodes})
+    ep_cpu = make_episodes(shape, seed_offset=1000 * rank)
+    state_cpu = make_estimator_state(shape.K, shape.c)
+    fdt = torch.bfloat16 if shape.feat_dtype == "bf16" else torch.float32
+    sF = 2 if fdt == torch.bfloat16 else 4
+    ep = {k: v.to(dev).contiguous() for k, v in ep_cpu.items()}
+    params = {k: v.to(dev).contiguous() for k, v in state_cpu.items()}
+    N, way = shape.N, shape.way
+    labels = ep["label"].reshape(N, way).contiguous()
+    eng = HeadStepEngine(N, way, shape.shot, shape.K, shape.c, shape.h, shape.w, shape.H, shape.W, dev, fdt)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.forward(ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params, with_grad=True)
+        eng.backward(ep["Fq"], labels, params)
+        if world > 1:
+            dist.all_reduce(eng.grad_bucket, op=dist.ReduceOp.AVG)
+
+    # ---- warm-up (also loads code objects, sets LDS attributes) ----
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- per-kernel breakdown (untimed): HIP events around each kernel in turn ----
+    kb = kernel_bytes(shape, sF)
+    breakdown = {}
+    if args.breakdown or args.probe == "auto":
+        e0, e1 = Event(), Event()
+        for name in _lib.KERNEL_IDS:
+            ts = []
+            eng.set_probe(name, e0, e1)
+            for _ in range(10):
+                step()
+                e1.synchronize()
+                ts.append(e0.elapsed_ms(e1) * 1e3)
+            breakdown[name] = statistics.median(ts)
+        eng.set_probe(None, None, None)
+    probe = args.probe
+    if probe == "auto":
+        probe = max(breakdown, key=breakdown.get)
+    if probe == "none":
+        probe = None
+
+    runner = step
+    graph = None
+    if args.graph and world == 1:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        runner = graph.replay
+        runner()
+        torch.cuda.synchronize()
+
+    # ---- timed region ----
+    pairs = []
+    if probe and graph is None:
+        pairs = [(Event(), Event()) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if pairs:
+            eng.set_probe(probe, *pairs[i])
+        runner()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    eng.set_probe(None, None, None)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    probe_us = None
+    if pairs:
+        probe_us = statistics.mean(a.elapsed_ms(b) * 1e3 for a, b in pairs)
+    elif probe:
+        probe_us = breakdown.get(probe)
+
+    losses = eng.losses.cpu().tolist()
+    episodes = N * world * args.steps
+    value = episodes / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    roofline = None
+    if probe and probe_us:
+        ach = kb[probe] / (probe_us * 1e-6) / 1e9
+        roofline = {"kernel": probe, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": kb[probe], "us_per_launch": round(probe_us, 2)}
+    spb = step_bytes_per_episode(shape, sF)
+    step_roof = {"bytes_per_episode": spb, "achieved": round(value / world * spb / 1e9, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(value / world * spb / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import denet_oracle as O            # checker only: CPU baseline leg
+        nthreads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
+        torch.set_num_threads(nthreads)
+        ts = []
+        for i in range(4):
+            c0 = time.perf_counter()
+            O.head_step(ep_cpu["Fq"], ep_cpu["Fs"], ep_cpu["Ys"], ep_cpu["label"], ep_cpu["Yq"], ep_cpu["Yq_full"],
+                        ep_cpu["wgt"], state_cpu)
+            ts.append(time.perf_counter() - c0)
+        med = statistics.median(ts[1:])
+        cpu = {"value": round(N / med, 3), "unit": "episodes/s", "cores": nthreads, "kind": "port",
+               "sample": f"1 warm-up + 3 timed steps of the same {args.config} batch ({N} episodes), "
+                         f"oracle head_step (fwd + both losses + loss_k.backward), median {med * 1e3:.0f} ms/step"}
+
+    if rank == 0:
+        out = {
+            "metric": "DENet head episodes/sec fwd+bwd (1-way 5-shot)" if args.config == "C2"
+                      else f"DENet head episodes/sec fwd+bwd ({args.config})",
+            "value": round(value, 1), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if sF == 4 else "bf16-in/f32-acc",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {way}-way {shape.shot}-shot head fwd+bwd, K={shape.K}, "
+                                   f"features {shape.c}x{shape.h}x{shape.w}, labels {shape.H}x{shape.W}",
+                       "episodes_per_gpu": N, "global_batch": N * world, "parallelism": f"dp{world} (episode-sharded)",
+                       "graph_replay": bool(graph)},
+            "roofline": roofline, "step_roofline": step_roof, "cpu_baseline": cpu,
+            "kernels_us": {k: round(v, 2) for k, v in breakdown.items()},
+            "loss_k": losses[0], "loss_p": losses[1],
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

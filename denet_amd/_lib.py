@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libdenet_hip.so")
 
 F32, BF16 = 0, 1
 
-# signature table: p = device pointer (tensor / None), l = int64, i = int, f = float
+# signature table: p = device pointer (tensor / None), l = int64, i = int, f = float,
+# h = host pointer (ctypes object / None)
 # the trailing stream argument is appended automatically ("s").
 _SIGS = {
     "denet_mask_resize": "plllllpp",
@@ -35,8 +36,8 @@ _SIGS = {
     "denet_confmat_fused": "pp" "llllll" "p",
     "denet_binary_iou_counts": "pp" "ll" "p",
     "denet_binary_iou_counts_fused": "pp" "lllll" "p",
-    "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl",
-    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllll" "pp" "ppppppp" "pl",
+    "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl" "h",
+    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllll" "pp" "ppppppp" "pl" "h",
 }
 _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
@@ -45,7 +46,17 @@ _NOSTREAM = {
     "denet_classify_bwd_parts": (ctypes.c_int64, "l"),
     "denet_head_step_workspace": (ctypes.c_int64, "lllllll"),
 }
-_CT = {"p": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float}
+_CT = {"p": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
+
+
+class Probe(ctypes.Structure):
+    """denet_probe_t (include/denet_hip.h)."""
+    _fields_ = [("which", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("start", ctypes.c_void_p), ("stop", ctypes.c_void_p)]
+
+
+KERNEL_IDS = {"mask_resize": 1, "masked_sum_fwd": 2, "proto_extend_fwd": 3, "classify_fwd": 4, "wce_fwd": 5,
+              "focal_fwd": 6, "loss_finalize": 7, "classify_bwd": 8, "proto_extend_bwd": 9, "masked_sum_bwd": 10}
 
 EXPORTS = sorted(list(_SIGS) + list(_NOSTREAM))
 
@@ -104,6 +115,8 @@ def call(name: str, *args):
     for c, a in zip(sig, args):
         if c == "p":
             conv.append(_ptr(a))
+        elif c == "h":
+            conv.append(None if a is None else ctypes.cast(ctypes.pointer(a), ctypes.c_void_p))
         elif c == "f":
             conv.append(float(a))
         else:

@@ -1,5 +1,20 @@
 // Version / error-string entry points of libdenet_hip.so.
 #include "denet_common.hpp"
+#include <mutex>
+#include <unordered_map>
+
+int denet_ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return DENET_OK;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(kernel);
+    if (it != seen.end() && it->second >= bytes) return DENET_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return DENET_E_LAUNCH;
+    seen[kernel] = bytes;
+    return DENET_OK;
+}
 
 extern "C" const char* denet_version(void) { return "denet_hip 0.1 (gfx950)"; }
 

@@ -293,12 +293,7 @@ static inline bool c_ok(int64_t C) { return C == 64 || C == 128 || C == 256 || C
 
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t lds) {
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return DENET_E_LAUNCH;
-    }
-    return DENET_OK;
+    return denet_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
 }
 
 template <typename T>

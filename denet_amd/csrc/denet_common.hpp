@@ -77,3 +77,7 @@ template <> struct FeatIO<unsigned short> {
     static __device__ __forceinline__ float load(const unsigned short* p) { return bf16_to_f32(*p); }
     static __device__ __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_bf16(v); }
 };
+
+// Raise a kernel's dynamic-LDS limit above the 48 KiB default (host side, cached per kernel so
+// steady-state launches make no runtime call besides the launch itself).  Defined in api.hip.
+int denet_ensure_dynamic_lds(const void* kernel, size_t bytes);

@@ -52,6 +52,18 @@ extern "C" int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t sho
         if (rc__) return rc__; \
     } while (0)
 
+// Optional probe: bracket ONE of the step's kernels with caller-owned HIP events on the
+// launch stream, so a harness can time that kernel inside its own timed region.
+#define PROBED(id, x)                                                                                  \
+    do {                                                                                               \
+        const bool on__ = probe && probe->which == (id) && probe->start && probe->stop;                \
+        if (on__ && hipEventRecord((hipEvent_t)probe->start, (hipStream_t)stream) != hipSuccess)       \
+            return DENET_E_LAUNCH;                                                                     \
+        TRY(x);                                                                                        \
+        if (on__ && hipEventRecord((hipEvent_t)probe->stop, (hipStream_t)stream) != hipSuccess)        \
+            return DENET_E_LAUNCH;                                                                     \
+    } while (0)
+
 extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
                                    const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
                                    const float* wgt, const float* weight, const float* W1, const float* b1,
@@ -59,25 +71,32 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
                                    const float* gate_mask, const float* weight_mask, int64_t N, int64_t way,
                                    int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
                                    int with_grad, float* logits_full, float* logits_binary,
-                                   float* losses /*[2]: loss_k, loss_p*/, void* ws, int64_t ws_bytes, void* stream) {
+                                   float* losses /*[2]: loss_k, loss_p*/, void* ws, int64_t ws_bytes,
+                                   const denet_probe_t* probe, void* stream) {
     if (!ws || !logits_full || !logits_binary || !losses) return DENET_E_BADARG;
     if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
     HeadWs s = carve(ws, N, way, shot, K, C, h, w);
     if (ws_bytes < s.total) return DENET_E_WORKSPACE;
     const int64_t B = N * way * shot, P = h * w, NB = N * way;
-    TRY(denet_mask_resize(Ys, B, H, W, h, w, s.mask, s.cnt, stream));
-    TRY(denet_masked_sum_fwd(Fs, feat_dtype, s.mask, B, C, P, s.S, stream));
-    TRY(denet_proto_extend_fwd(s.S, s.cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, N, way,
-                               shot, K, C, P, s.hidden, s.gate, s.pool, s.Wn, stream));
-    TRY(denet_classify_fwd(Fq, feat_dtype, s.Wn, labels, N, way, K, C, P, 1, logits_full, logits_binary, stream));
+    PROBED(DENET_K_MASK_RESIZE, denet_mask_resize(Ys, B, H, W, h, w, s.mask, s.cnt, stream));
+    PROBED(DENET_K_MASKED_SUM_FWD, denet_masked_sum_fwd(Fs, feat_dtype, s.mask, B, C, P, s.S, stream));
+    PROBED(DENET_K_PROTO_EXTEND_FWD,
+           denet_proto_extend_fwd(s.S, s.cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, N, way,
+                                  shot, K, C, P, s.hidden, s.gate, s.pool, s.Wn, stream));
+    PROBED(DENET_K_CLASSIFY_FWD,
+           denet_classify_fwd(Fq, feat_dtype, s.Wn, labels, N, way, K, C, P, 1, logits_full, logits_binary, stream));
     if (Yq_full) {
-        TRY(denet_upsample_wce_fwd(logits_full, Yq_full, wgt, N, K, h, w, H, W, s.part_k,
-                                   with_grad ? s.dlog_a : nullptr, with_grad ? s.dlog_b : nullptr, stream));
+        PROBED(DENET_K_WCE_FWD,
+               denet_upsample_wce_fwd(logits_full, Yq_full, wgt, N, K, h, w, H, W, s.part_k,
+                                      with_grad ? s.dlog_a : nullptr, with_grad ? s.dlog_b : nullptr, stream));
     }
-    if (Yq) TRY(denet_upsample_focal_fwd(logits_binary, Yq, NB, h, w, H, W, 0.25f, 2.f, s.part_p, stream));
+    if (Yq)
+        PROBED(DENET_K_FOCAL_FWD,
+               denet_upsample_focal_fwd(logits_binary, Yq, NB, h, w, H, W, 0.25f, 2.f, s.part_p, stream));
     if (Yq_full || Yq)
-        TRY(denet_loss_finalize(Yq_full ? s.part_k : nullptr, Yq ? s.part_p : nullptr, N, NB, h, 0, losses, nullptr,
-                                s.scale, stream));
+        PROBED(DENET_K_LOSS_FINALIZE,
+               denet_loss_finalize(Yq_full ? s.part_k : nullptr, Yq ? s.part_p : nullptr, N, NB, h, 0, losses,
+                                   nullptr, s.scale, stream));
     return DENET_OK;
 }
 
@@ -86,18 +105,21 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
                                    const float* weight_mask, const float* grad_loss_k /*device scalar or NULL*/,
                                    int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                                    void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
-                                   float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes, void* stream) {
+                                   float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes,
+                                   const denet_probe_t* probe, void* stream) {
     if (!ws || !dFq || !dFs) return DENET_E_BADARG;
     if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
     HeadWs s = carve(ws, N, way, shot, K, C, h, w);
     if (ws_bytes < s.total) return DENET_E_WORKSPACE;
     const int64_t B = N * way * shot, P = h * w;
     const int64_t n_part = denet_classify_bwd_parts(P);
-    TRY(denet_classify_bwd(Fq, feat_dtype, s.Wn, s.dlog_a, s.dlog_b, s.scale, grad_loss_k, N, K, C, P, dFq,
-                           s.dWn_part, stream));
-    TRY(denet_proto_extend_bwd(s.dWn_part, n_part, s.S, s.cnt, s.hidden, s.gate, s.pool, W1, W2, Wl, labels,
-                               gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl, dweight,
-                               s.coef, s.u, 3 * B * C * 4, stream));
-    TRY(denet_masked_sum_bwd(s.mask, s.coef, B, C, P, dFs, feat_dtype, stream));
+    PROBED(DENET_K_CLASSIFY_BWD,
+           denet_classify_bwd(Fq, feat_dtype, s.Wn, s.dlog_a, s.dlog_b, s.scale, grad_loss_k, N, K, C, P, dFq,
+                              s.dWn_part, stream));
+    PROBED(DENET_K_PROTO_EXTEND_BWD,
+           denet_proto_extend_bwd(s.dWn_part, n_part, s.S, s.cnt, s.hidden, s.gate, s.pool, W1, W2, Wl, labels,
+                                  gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl,
+                                  dweight, s.coef, s.u, 3 * B * C * 4, stream));
+    PROBED(DENET_K_MASKED_SUM_BWD, denet_masked_sum_bwd(s.mask, s.coef, B, C, P, dFs, feat_dtype, stream));
     return DENET_OK;
 }

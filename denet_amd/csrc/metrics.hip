@@ -197,10 +197,7 @@ extern "C" int denet_confmat(const float* preds, const int64_t* label_true, int6
     unsigned gx;
     const int chunk = pick_chunk(HW, N, &gx);
     const size_t lds = (size_t)K * K * 4;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(confmat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return DENET_E_LAUNCH;
+    if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(confmat_kernel), lds)) return DENET_E_LAUNCH;
     hipLaunchKernelGGL(confmat_kernel, dim3(gx, (unsigned)N), dim3(MT_THREADS), lds, (hipStream_t)stream, preds,
                        label_true, (int)K, HW, chunk, (unsigned long long*)mat);
     DENET_CHECK_LAUNCH();
@@ -227,9 +224,7 @@ extern "C" int denet_confmat_fused(const float* logits, const int64_t* label_tru
     if (K > 128 || N > 65535) return DENET_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * K * w * 4 + (size_t)K * K * 4 + 128;
     if (lds > 160 * 1024) return DENET_E_UNSUPPORTED;
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(fused_metric_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(fused_metric_kernel<false>), lds))
         return DENET_E_LAUNCH;
     hipLaunchKernelGGL(fused_metric_kernel<false>, dim3((unsigned)h, (unsigned)N), dim3(MT_THREADS), lds,
                        (hipStream_t)stream, logits, label_true, (int)K, (int)h, (int)w, (int)H, (int)W,

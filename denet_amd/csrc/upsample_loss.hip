@@ -295,12 +295,7 @@ static int band_rows_bound(int64_t h, int64_t H) {
 
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t lds) {
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return DENET_E_LAUNCH;
-    }
-    return DENET_OK;
+    return denet_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
 }
 
 static int launch_loss(int mode, bool grad, const float* logits, const int64_t* Y, const float* wgt, int64_t N,

@@ -1,0 +1,70 @@
+"""Allocation-free driver of the fused head step (include/denet_hip.h, T1).
+
+All device buffers (workspace, logits, losses, gradients) are allocated once;
+`forward()` / `backward()` only enqueue kernels on torch's current stream.  The
+seven parameter gradients live in ONE flat fp32 bucket so that data-parallel
+training needs a single RCCL all-reduce per step.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, feat_code, query
+
+PARAM_ORDER = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+               "map.linear.weight", "map.linear.bias"]
+
+
+class HeadStepEngine:
+    def __init__(self, N, way, shot, K, C, h, w, H, W, device, feat_dtype=torch.float32):
+        self.dims = (N, way, shot, K, C, h, w, H, W)
+        self.device = device
+        self.feat_dtype = feat_dtype
+        f32 = dict(dtype=torch.float32, device=device)
+        self.ws_bytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.logits_full = torch.empty(N, K, h, w, **f32)
+        self.logits_binary = torch.empty(N * way, 2, h, w, **f32)
+        self.losses = torch.zeros(2, **f32)
+        self.dFq = torch.empty(N, C, h, w, dtype=feat_dtype, device=device)
+        self.dFs = torch.empty(N, way, shot, C, h, w, dtype=feat_dtype, device=device)
+        sizes = [K * C, C * C, C, C * C, C, C * C, C]
+        self.grad_bucket = torch.zeros(sum(sizes), **f32)
+        self.grads = {}
+        off = 0
+        shapes = [(K, C), (C, C, 1, 1), (C,), (C, C, 1, 1), (C,), (C, C, 1, 1), (C,)]
+        for name, n, shp in zip(PARAM_ORDER, sizes, shapes):
+            self.grads[name] = self.grad_bucket[off:off + n].view(shp)
+            off += n
+        self._probe = None
+
+    def set_probe(self, which, start_event, stop_event):
+        """Bracket kernel `which` (a name in _lib.KERNEL_IDS, or None) with HIP events."""
+        if which is None:
+            self._probe = None
+            return
+        p = _lib.Probe()
+        p.which = _lib.KERNEL_IDS[which]
+        p.start = start_event.h
+        p.stop = stop_event.h
+        self._probe = p
+
+    def forward(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
+                with_grad=True):
+        N, way, shot, K, C, h, w, H, W = self.dims
+        P = [params[k] for k in PARAM_ORDER]
+        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask, weight_mask,
+             N, way, shot, K, C, h, w, H, W, 1 if with_grad else 0, self.logits_full, self.logits_binary,
+             self.losses, self.ws, self.ws_bytes, self._probe)
+
+    def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None):
+        N, way, shot, K, C, h, w, H, W = self.dims
+        g = self.grads
+        call("denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
+             params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
+             N, way, shot, K, C, h, w, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
+             g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
+             g["map.linear.bias"], self.ws, self.ws_bytes, self._probe)

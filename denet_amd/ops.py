@@ -325,7 +325,7 @@ class HeadStepFunction(torch.autograd.Function):
         losses = torch.zeros(2, dtype=torch.float32, device=dev)
         call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *params,
              gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
-             ws, nbytes)
+             ws, nbytes, None)
         ctx.dims = (N, way, shot, K, C, h, w)
         ctx.ws = ws
         ctx.fs_shape = Fs.shape
@@ -355,5 +355,5 @@ class HeadStepFunction(torch.autograd.Function):
         db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
         g = g_k.contiguous().float().reshape(1)
         call("denet_head_step_bwd", Fq, feat_code(Fq), labels, W1, W2, Wl, gate_mask, weight_mask, g,
-             N, way, shot, K, C, h, w, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws, ctx.ws.numel())
+             N, way, shot, K, C, h, w, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws, ctx.ws.numel(), None)
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7

@@ -194,7 +194,28 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
  * shared by the two calls of one step.  Yq / Yq_full may be NULL (test mode:
  * no loss, trainer/trainers.py:958).  losses = {loss_k, loss_p} on device.
  * grad_loss_k: device scalar d(objective)/d(loss_k), NULL = 1.  Only loss_k is
- * back-propagated (trainer/trainers.py:972-974). */
+ * back-propagated (trainer/trainers.py:972-974).
+ *
+ * probe (HOST pointer, may be NULL): brackets ONE kernel of the step with the
+ * caller's HIP events, recorded on `stream`, so a harness can time that kernel
+ * inside its own timed region (bench.py's roofline line). */
+#define DENET_K_MASK_RESIZE      1
+#define DENET_K_MASKED_SUM_FWD   2
+#define DENET_K_PROTO_EXTEND_FWD 3
+#define DENET_K_CLASSIFY_FWD     4
+#define DENET_K_WCE_FWD          5
+#define DENET_K_FOCAL_FWD        6
+#define DENET_K_LOSS_FINALIZE    7
+#define DENET_K_CLASSIFY_BWD     8
+#define DENET_K_PROTO_EXTEND_BWD 9   /* two launches: chain + parameter gradients */
+#define DENET_K_MASKED_SUM_BWD   10
+typedef struct denet_probe {
+    int32_t which;      /* DENET_K_* */
+    int32_t reserved;
+    void* start;        /* hipEvent_t */
+    void* stop;         /* hipEvent_t */
+} denet_probe_t;
+
 int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
                                   int64_t h, int64_t w);
 int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
@@ -205,13 +226,14 @@ int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const in
                         int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
                         int64_t h, int64_t w, int64_t H, int64_t W, int with_grad,
                         float* logits_full, float* logits_binary, float* losses,
-                        void* ws, int64_t ws_bytes, void* stream);
+                        void* ws, int64_t ws_bytes, const denet_probe_t* probe, void* stream);
 int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
                         const float* W1, const float* W2, const float* Wl,
                         const float* gate_mask, const float* weight_mask, const float* grad_loss_k,
                         int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                         void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
-                        float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes, void* stream);
+                        float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes,
+                        const denet_probe_t* probe, void* stream);
 
 #ifdef __cplusplus
 }
