@@ -29,7 +29,7 @@ _SIGS = {
     "denet_classify_bwd": "pip" "pppp" "llll" "pp",
     "denet_upsample_wce_fwd": "ppp" "llllll" "ppp",
     "denet_upsample_focal_fwd": "pp" "lllll" "ff" "p",
-    "denet_loss_finalize": "pp" "lll" "i" "ppp",
+    "denet_loss_finalize": "pp" "llll" "i" "ppp",
     "denet_combine_slabs": "pppp" "ll" "p",
     "denet_upsample_bilinear": "p" "lllll" "p",
     "denet_confmat": "pp" "lll" "p",
@@ -37,14 +37,15 @@ _SIGS = {
     "denet_binary_iou_counts": "pp" "ll" "p",
     "denet_binary_iou_counts_fused": "pp" "lllll" "p",
     "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl" "h",
-    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllll" "pp" "ppppppp" "pl" "h",
+    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllllll" "pp" "ppppppp" "pl" "h",
 }
 _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
     "denet_strerror": (ctypes.c_char_p, "i"),
-    "denet_proto_extend_bwd_workspace": (ctypes.c_int64, "ll"),
+    "denet_proto_extend_bwd_workspace": (ctypes.c_int64, "lllll"),
     "denet_classify_bwd_parts": (ctypes.c_int64, "l"),
-    "denet_head_step_workspace": (ctypes.c_int64, "lllllll"),
+    "denet_head_step_workspace": (ctypes.c_int64, "lllllllll"),
+    "denet_upsample_loss_parts": (ctypes.c_int64, "llllli"),
 }
 _CT = {"p": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
 

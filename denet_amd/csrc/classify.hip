@@ -52,7 +52,7 @@ __device__ __forceinline__ void load2<unsigned short>(const unsigned short* p, b
     }
 }
 
-template <typename T, int RT>
+template <typename T, int RT, int NLD>
 __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
                                                           int64_t wn_stride, const int64_t* __restrict__ labels,
                                                           int way, int K, int C, int P, int base,
@@ -63,15 +63,46 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     const int j = lane & 31, hh = lane >> 5;
     const int ldw = C + 1;
 
-    // stage Wn[n] -> LDS [K][C+1]
+    const int cper = C >> 2;                       // channels per wave: 16, 32, 64 or 128
+    const int cbeg = wave * cper;
+    const int pa = p0 + 2 * j;
+    const bool ok0 = pa < P, ok1 = pa + 1 < P;
+    const bool fast = (p0 + CL_TP <= P);
+    const T* fq = Fq + (int64_t)n * C * P + pa;
+    // The streamed operand first: up to 64 channels (32 k-steps, 16 KB per wave) of Fq go in flight
+    // before anything else, so the Wn staging below hides under their latency.
+    STAMP(0);
+    constexpr int chunk = 2 * NLD;                 // channels per pass of this wave (== cper: C is 64 or 256)
+    float b0[NLD], b1[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) load2<T>(fq + (int64_t)(cbeg + 2 * u + hh) * P, ok0, ok1, fast, b0[u], b1[u]);
+
+    // stage Wn[n] -> LDS [K][C+1]: 16-byte loads, all of a thread's loads issued before the first store
     {
         const float* src = Wn + (int64_t)n * wn_stride;
-        for (int idx = tid; idx < K * C; idx += 256) {
-            const int k = idx / C, c = idx - k * C;
-            sm[k * ldw + c] = src[idx];
+        const int nv = (K * C) >> 2;
+#pragma unroll 1
+        for (int base = 0; base < nv; base += 256 * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = base + u * 256 + tid;
+                if (i4 < nv) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)i4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = base + u * 256 + tid;
+                if (i4 < nv) {
+                    const int idx = i4 * 4;
+                    const int k = idx / C, c = idx - k * C;
+                    float* d = sm + k * ldw + c;
+                    d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+                }
+            }
         }
     }
     __syncthreads();
+    STAMP(1);
 
     f32x16 acc[RT][2];
 #pragma unroll
@@ -80,13 +111,6 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][t][e] = 0.f;
-
-    const int cper = C >> 2;                       // channels per wave (multiple of 16)
-    const int cbeg = wave * cper;
-    const int pa = p0 + 2 * j;
-    const bool ok0 = pa < P, ok1 = pa + 1 < P;
-    const bool fast = (p0 + CL_TP <= P);
-    const T* fq = Fq + (int64_t)n * C * P + pa;
     int arow[RT];
     bool aok[RT];
 #pragma unroll
@@ -96,19 +120,9 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         arow[rt] = (aok[rt] ? row : K - 1) * ldw;
     }
 
-    // software pipeline: the next 16 channels' loads are in flight under this step's 16*RT MFMAs
-    float b0[8], b1[8], nb0[8], nb1[8];
+    for (int c = cbeg; c < cbeg + cper; c += chunk) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        load2<T>(fq + (int64_t)(cbeg + 2 * u + hh) * P, ok0, ok1, fast, b0[u], b1[u]);
-    for (int c = cbeg; c < cbeg + cper; c += 16) {
-        if (c + 16 < cbeg + cper) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                load2<T>(fq + (int64_t)(c + 16 + 2 * u + hh) * P, ok0, ok1, fast, nb0[u], nb1[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NLD; ++u) {
             const int cc = c + 2 * u + hh;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -118,9 +132,13 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                 acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[u], acc[rt][1], 0, 0, 0);
             }
         }
+        if (c + chunk < cbeg + cper) {             // only if a wave owns more than one chunk
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { b0[u] = nb0[u]; b1[u] = nb1[u]; }
+            for (int u = 0; u < NLD; ++u)
+                load2<T>(fq + (int64_t)(c + chunk + 2 * u + hh) * P, ok0, ok1, fast, b0[u], b1[u]);
+        }
     }
+    STAMP(2);
     __syncthreads();            // all waves done with the Wn tile; LDS is reused for the partials
 
     // partial tiles: part[wave][k][CL_LD]
@@ -149,6 +167,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
             if (p < P) logits[((int64_t)n * K + k) * P + p] = v;
         }
     }
+    STAMP(3);
     if (bin == nullptr) return;
     __syncthreads();
     // binary logits: ch1 = row label, ch0 = max over the other rows (utils/operations.py:327-337)
@@ -170,6 +189,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         dst[0] = bg;
         dst[P] = fg;
     }
+    STAMP(4);
 }
 
 // ---------------------------------------------------------------------------
@@ -195,38 +215,98 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__
     const int j = lane & 31, hh = lane >> 5;
     const int KP = (K + 1) & ~1;
     const float sc = (scale ? scale[n] : 1.f) * (gmul ? gmul[0] : 1.f);
-    for (int idx = tid; idx < KP * CL_TP; idx += 256) {
-        const int k = idx >> 6, col = idx & 63;
-        const int p = p0 + col;
-        float v = 0.f;
-        if (k < K && p < P) {
-            const int64_t gi = ((int64_t)n * K + k) * P + p;
-            v = dlog_a[gi];
-            if (dlog_b) v += dlog_b[gi];
-            v *= sc;
-        }
-        sm[k * CL_LD + col] = v;
-    }
-    __syncthreads();
-
     const float* wn = Wn + (int64_t)n * K * C;
     const bool fast = (p0 + CL_TP <= P);
-    const int nct = C >> 5;
+    const int nct = C >> 5;                      // 32-channel tiles: 2 (C=64) or 8 (C=256); <= 2 per wave
+    constexpr int NA = RT * 16;
+    // With K <= 32 every global operand of this block fits in registers, so ALL of them are
+    // requested before the first wait: the block then pays one memory latency, not five.
+    constexpr bool PRE = (RT == 1);
+    float av[2][PRE ? NA : 1];
+    float fv[2][PRE ? 32 : 1];
+
+    auto load_av = [&](int ct, float* dst) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int kk = 2 * u + hh;
+            dst[u] = kk < K ? wn[(int64_t)kk * C + ct * 32 + j] : 0.f;
+        }
+    };
+    auto load_fv = [&](int ct, float* dst) {
+        const int pb = p0 + 32 * hh;
+        const T* src = Fq + ((int64_t)n * C + ct * 32 + j) * P + pb;
+        if (fast) {
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)src + 4 * m);
+                    dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 32; ++s) dst[s] = FeatIO<T>::load(src + s);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) dst[s] = (pb + s < P) ? FeatIO<T>::load(src + s) : 0.f;
+        }
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct < nct) {
+                if (dFq != nullptr) load_av(ct, av[i]);
+                if (dWn_part != nullptr) load_fv(ct, fv[i]);
+            }
+        }
+    }
+
+#pragma unroll 1
+    for (int base = 0; base < KP * CL_TP; base += 256 * 6) {
+        float va[6], vb[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int k = idx >> 6, col = idx & 63;
+            const int p = p0 + col;
+            va[u] = 0.f; vb[u] = 0.f;
+            if (idx < KP * CL_TP && k < K && p < P) {
+                const int64_t gi = ((int64_t)n * K + k) * P + p;
+                va[u] = dlog_a[gi];
+                if (dlog_b) vb[u] = dlog_b[gi];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < KP * CL_TP) sm[(idx >> 6) * CL_LD + (idx & 63)] = (va[u] + vb[u]) * sc;
+        }
+    }
+    __syncthreads();
 
     // ---- dFq ----
     if (dFq != nullptr) {
         const int pa = p0 + 2 * j;
-        for (int ct = wave; ct < nct; ct += 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct >= nct) continue;
             const int c0 = ct * 32;
             f32x16 a0, a1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-            for (int ks = 0; ks < KP; ks += 2) {
-                const int kk = ks + hh;
-                const float a = kk < K ? wn[(int64_t)kk * C + c0 + j] : 0.f;
-                const f32x2 b = *reinterpret_cast<const f32x2*>(sm + kk * CL_LD + 2 * j);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], a1, 0, 0, 0);
+            float avl[NA];
+            if constexpr (!PRE) load_av(ct, avl);
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int kk = 2 * u + hh;
+                if (2 * u < KP) {
+                    const float a = PRE ? av[i][PRE ? u : 0] : avl[u];
+                    const f32x2 b = *reinterpret_cast<const f32x2*>(sm + kk * CL_LD + 2 * j);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], a1, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -240,26 +320,13 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__
 
     // ---- dWn partial ----
     if (dWn_part != nullptr) {
-        for (int ct = wave; ct < nct; ct += 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct >= nct) continue;
             const int c0 = ct * 32;
-            const int pb = p0 + 32 * hh;
-            const T* src = Fq + ((int64_t)n * C + c0 + j) * P + pb;
-            float fv[32];
-            if (fast) {
-                if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)src + 4 * m);
-                        fv[4 * m] = v[0]; fv[4 * m + 1] = v[1]; fv[4 * m + 2] = v[2]; fv[4 * m + 3] = v[3];
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 32; ++s) fv[s] = FeatIO<T>::load(src + s);
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 32; ++s) fv[s] = (pb + s < P) ? FeatIO<T>::load(src + s) : 0.f;
-            }
+            float fvl[32];
+            if constexpr (!PRE) load_fv(ct, fvl);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const int row = 32 * rt + j;
@@ -272,7 +339,8 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__
                 for (int s = 0; s < 32; ++s) {
                     float a = arow[s];
                     a = ok ? a : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fv[s], acc, 0, 0, 0);
+                    const float bq = PRE ? fv[i][PRE ? s : 0] : fvl[s];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -289,7 +357,7 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__
 // C ABI
 // ---------------------------------------------------------------------------
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
-static inline bool c_ok(int64_t C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+static inline bool c_ok(int64_t C) { return C == 64 || C == 256; }
 
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t lds) {
@@ -305,13 +373,15 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
     const size_t lds = (a > b ? a : b) * 4;
     if (lds > 160 * 1024) return DENET_E_UNSUPPORTED;
     dim3 grid((unsigned)((P + CL_TP - 1) / CL_TP), (unsigned)N), block(256);
-#define CL_FWD(R)                                                                                           \
+#define CL_FWD2(R, L)                                                                                       \
     {                                                                                                       \
-        int rc = set_lds(classify_fwd_kernel<T, R>, lds);                                                   \
+        int rc = set_lds(classify_fwd_kernel<T, R, L>, lds);                                                \
         if (rc) return rc;                                                                                  \
-        hipLaunchKernelGGL((classify_fwd_kernel<T, R>), grid, block, lds, st, Fq, Wn, wn_stride, labels,    \
+        hipLaunchKernelGGL((classify_fwd_kernel<T, R, L>), grid, block, lds, st, Fq, Wn, wn_stride, labels, \
                            (int)way, (int)K, (int)C, (int)P, base, logits, bin);                            \
     }
+#define CL_FWD(R)                       \
+    if (C == 64) CL_FWD2(R, 8) else CL_FWD2(R, 32)
     switch (RT) {
         case 1: CL_FWD(1); break;
         case 2: CL_FWD(2); break;
@@ -319,6 +389,7 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
         case 4: CL_FWD(4); break;
         default: return DENET_E_UNSUPPORTED;
     }
+#undef CL_FWD2
 #undef CL_FWD
     DENET_CHECK_LAUNCH();
     return DENET_OK;

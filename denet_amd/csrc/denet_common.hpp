@@ -40,20 +40,33 @@ __device__ __forceinline__ void bilinear_tap(int dst, float scale, int in_size, 
 }
 
 // ---- wave / block reductions -------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// DPP forms: the cross-lane operand is read by the VALU itself (no LDS-path ds_bpermute, which
+// costs ~100+ cycles of dependent latency per step).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_f32<0x141>(v);    // row_half_mirror      (other quad of the half row)
+    v += dpp_f32<0x140>(v);    // row_mirror           (other half of the row)
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    // combine the four rows: two readlane-free steps through ds_swizzle-less shuffles would need
+    // LDS; use v_readlane (scalar broadcast) instead: 4 reads + 3 adds, all lanes get the total
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-// sum over the 16 lanes of a DPP row (lanes sharing lane>>4)
-__device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
@@ -81,3 +94,11 @@ template <> struct FeatIO<unsigned short> {
 // Raise a kernel's dynamic-LDS limit above the 48 KiB default (host side, cached per kernel so
 // steady-state launches make no runtime call besides the launch itself).  Defined in api.hip.
 int denet_ensure_dynamic_lds(const void* kernel, size_t bytes);
+
+// Diagnostic builds only (scripts/diag): phase stamps of block 0 / thread 0 into a debug buffer.
+#ifdef DENET_STAMPS
+__device__ unsigned long long* g_stamps;
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif

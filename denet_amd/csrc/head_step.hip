@@ -13,7 +13,8 @@ struct HeadWs {
 
 static inline int64_t al(int64_t n) { return (n + 63) & ~(int64_t)63; }   // floats, 256-B granules
 
-static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w) {
+static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                    int64_t parts_k, int64_t parts_p) {
     const int64_t B = N * way * shot, P = h * w, NB = N * way;
     const int64_t n_part = denet_classify_bwd_parts(P);
     float* p = (float*)base;
@@ -27,23 +28,26 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
     TAKE(gate, B * C);
     TAKE(pool, B * C);
     TAKE(Wn, N * K * C);
-    TAKE(part_k, N * h * 2);
-    TAKE(part_p, NB * h * 2);
+    TAKE(part_k, N * parts_k * 2);
+    TAKE(part_p, NB * parts_p * 2);
     TAKE(scale, N);
     TAKE(dlog_a, N * K * P);
     TAKE(dlog_b, N * K * P);
     TAKE(dWn_part, N * n_part * K * C);
     TAKE(coef, B * C);
-    TAKE(u, 3 * B * C);
+    TAKE(u, 3 * B * C + N * K * C);
 #undef TAKE
     s.total = off * 4;
     return s;
 }
 
 extern "C" int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h,
-                                             int64_t w) {
-    if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
-    return carve(nullptr, N, way, shot, K, C, h, w).total;
+                                             int64_t w, int64_t H, int64_t W) {
+    if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return DENET_E_BADARG;
+    const int64_t pk = denet_upsample_loss_parts(K, h, w, H, W, 1), pp = denet_upsample_loss_parts(2, h, w, H, W, 0);
+    if (pk < 0 || pp < 0) return DENET_E_UNSUPPORTED;
+    return carve(nullptr, N, way, shot, K, C, h, w, pk, pp).total;
 }
 
 #define TRY(x)                 \
@@ -75,9 +79,13 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
                                    const denet_probe_t* probe, void* stream) {
     if (!ws || !logits_full || !logits_binary || !losses) return DENET_E_BADARG;
     if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
-    HeadWs s = carve(ws, N, way, shot, K, C, h, w);
+    const int64_t pk = denet_upsample_loss_parts(K, h, w, H, W, 1), pp = denet_upsample_loss_parts(2, h, w, H, W, 0);
+    if (pk < 0 || pp < 0) return DENET_E_UNSUPPORTED;
+    HeadWs s = carve(ws, N, way, shot, K, C, h, w, pk, pp);
     if (ws_bytes < s.total) return DENET_E_WORKSPACE;
     const int64_t B = N * way * shot, P = h * w, NB = N * way;
+    // the grad and no-grad variants of the CE kernel may tile the columns differently
+    const int64_t pk_run = with_grad ? pk : denet_upsample_loss_parts(K, h, w, H, W, 0);
     PROBED(DENET_K_MASK_RESIZE, denet_mask_resize(Ys, B, H, W, h, w, s.mask, s.cnt, stream));
     PROBED(DENET_K_MASKED_SUM_FWD, denet_masked_sum_fwd(Fs, feat_dtype, s.mask, B, C, P, s.S, stream));
     PROBED(DENET_K_PROTO_EXTEND_FWD,
@@ -95,8 +103,8 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
                denet_upsample_focal_fwd(logits_binary, Yq, NB, h, w, H, W, 0.25f, 2.f, s.part_p, stream));
     if (Yq_full || Yq)
         PROBED(DENET_K_LOSS_FINALIZE,
-               denet_loss_finalize(Yq_full ? s.part_k : nullptr, Yq ? s.part_p : nullptr, N, NB, h, 0, losses,
-                                   nullptr, s.scale, stream));
+               denet_loss_finalize(Yq_full ? s.part_k : nullptr, Yq ? s.part_p : nullptr, N, NB, pk_run, pp, 0,
+                                   losses, nullptr, s.scale, stream));
     return DENET_OK;
 }
 
@@ -104,12 +112,14 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
                                    const float* W2, const float* Wl, const float* gate_mask,
                                    const float* weight_mask, const float* grad_loss_k /*device scalar or NULL*/,
                                    int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
-                                   void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
+                                   int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
                                    float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes,
                                    const denet_probe_t* probe, void* stream) {
     if (!ws || !dFq || !dFs) return DENET_E_BADARG;
     if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
-    HeadWs s = carve(ws, N, way, shot, K, C, h, w);
+    const int64_t pk = denet_upsample_loss_parts(K, h, w, H, W, 1), pp = denet_upsample_loss_parts(2, h, w, H, W, 0);
+    if (pk < 0 || pp < 0) return DENET_E_UNSUPPORTED;
+    HeadWs s = carve(ws, N, way, shot, K, C, h, w, pk, pp);
     if (ws_bytes < s.total) return DENET_E_WORKSPACE;
     const int64_t B = N * way * shot, P = h * w;
     const int64_t n_part = denet_classify_bwd_parts(P);
@@ -119,7 +129,7 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     PROBED(DENET_K_PROTO_EXTEND_BWD,
            denet_proto_extend_bwd(s.dWn_part, n_part, s.S, s.cnt, s.hidden, s.gate, s.pool, W1, W2, Wl, labels,
                                   gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl,
-                                  dweight, s.coef, s.u, 3 * B * C * 4, stream));
+                                  dweight, s.coef, s.u, (3 * B * C + N * K * C) * 4, stream));
     PROBED(DENET_K_MASKED_SUM_BWD, denet_masked_sum_bwd(s.mask, s.coef, B, C, P, dFs, feat_dtype, stream));
     return DENET_OK;
 }

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void mask_resize_kernel(const int64_t* __restr
     const float sy = nearest_scale(H, h), sx = nearest_scale(W, w);
     const int64_t* src = Ys + (int64_t)b * H * W;
     float acc = 0.f;
+#pragma unroll 8
     for (int p = threadIdx.x; p < P; p += 256) {
         int y = p / w, x = p - y * w;
         int yy = nearest_src(y, sy, H), xx = nearest_src(x, sx, W);
@@ -65,6 +66,9 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
     const int c0 = blockIdx.x * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* mrow = mask + (int64_t)b * P;
+    // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
+    // latency once per iteration)
+#pragma unroll 8
     for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
     __syncthreads();
 
@@ -106,6 +110,9 @@ __global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __rest
     const int c0 = blockIdx.x * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* mrow = mask + (int64_t)b * P;
+    // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
+    // latency once per iteration)
+#pragma unroll 8
     for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
     __syncthreads();
 

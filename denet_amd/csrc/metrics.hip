@@ -110,6 +110,7 @@ __global__ __launch_bounds__(MT_THREADS) void fused_metric_kernel(const float* _
     const float sy = bilinear_scale(h, H), sx = bilinear_scale(w, W);
     const int ys = first_dst_ge_m(py, sy, h, H), ye = first_dst_ge_m(py + 1, sy, h, H);
     const float* src = logits + (int64_t)n * K * h * w;
+#pragma unroll 4
     for (int idx = tid; idx < kw; idx += MT_THREADS) {
         const int k = idx / w, x = idx - k * w;
         lg0[idx] = src[((int64_t)k * h + py) * w + x];
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(MT_THREADS) void fused_metric_kernel(const float* _
     long long st = 0;
     unsigned int inter = 0, uni = 0;
     const int npix = (ye - ys) * W;
+#pragma unroll 2
     for (int i = tid; i < npix; i += MT_THREADS) {
         const int r = i / W, qx = i - r * W;
         const int qy = ys + r;

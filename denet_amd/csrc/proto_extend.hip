@@ -16,44 +16,52 @@
 #include "denet_common.hpp"
 
 #define PE_THREADS 512
+
 #define PE_EPS 1e-3f      // model/common.py:170
 
-// y[s][o] = b[o] + sum_i W[o][i] * xs[s][i]   for s < shot, o < C ; result handed to epi(o, s, y)
-template <int CJ, typename Epi>
-__device__ __forceinline__ void dense_rows(const float* __restrict__ W, const float* __restrict__ bias,
-                                           const float* xs, int shot, Epi epi) {
+// ---------------------------------------------------------------------------
+// Forward.  1024 threads = 16 waves; a wave covers 4 weight rows per step, 16 lanes per row
+// (16-byte loads along the row, coalesced 256-B segments), so one step of the block covers 64 rows
+// and a C x C layer is C/64 steps.  The three layers form ONE sequence of 3*C/64 steps whose weight
+// loads run through a 4-slot register ring, three steps ahead of the FMAs and across the layer
+// boundaries (the weights do not depend on the activations), so the block pays the memory latency
+// once instead of once per step.  Activations come from LDS; bias, activation and the global
+// stores happen in a block-wide pass at each layer boundary.  The step loop is fully unrolled
+// (trip count is a template constant), which keeps every ring index static.
+// ---------------------------------------------------------------------------
+#define PF_THREADS 1024
+#define PF_ROWS (PF_THREADS / 16)      // weight rows covered by one step of the block
+#define PF_DEPTH 3
+
+// z[s][o] = sum_i W[o][i] * xs[s][i]  for the 4 rows of this wave in step `it`, s < NS (no bias)
+template <int CJ, int NS>
+__device__ __forceinline__ void layer_step(const f32x4 (&wv)[CJ], const float* xs, float* z, int it) {
     constexpr int C = CJ * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane >> 4, q = lane & 15;
-    f32x4 wv[CJ], wn[CJ];
-    int o = wave * 4 + r;
+    float acc[NS];
 #pragma unroll
-    for (int j = 0; j < CJ; ++j) wv[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)o * C + q * 4 + 64 * j);
-    for (; o < C; o += 32) {
-        const int on = o + 32;
-        if (on < C) {
+    for (int s = 0; s < NS; ++s) {
+        float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < CJ; ++j)
-                wn[j] = *reinterpret_cast<const f32x4*>(W + (int64_t)on * C + q * 4 + 64 * j);
+        for (int j = 0; j < CJ; ++j) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + s * C + q * 4 + 64 * j);
+            a += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
         }
-        const float bo = bias[o];
-        for (int s = 0; s < shot; ++s) {
-            float acc = 0.f;
+        acc[s] = a;
+    }
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) {
-                f32x4 xv = *reinterpret_cast<const f32x4*>(xs + s * C + q * 4 + 64 * j);
-                acc += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
-            }
-            acc = row16_sum(acc);
-            if (q == 0) epi(o, s, acc + bo);
-        }
+    for (int s = 0; s < NS; ++s) acc[s] = row16_sum(acc[s]);
+    if (q == 0) {
+        const int o = it * PF_ROWS + wave * 4 + r;
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) wv[j] = wn[j];
+        for (int s = 0; s < NS; ++s) z[s * C + o] = acc[s];
     }
 }
 
-template <int CJ>
-__global__ __launch_bounds__(PE_THREADS) void proto_extend_fwd_kernel(
+// NS >= shot: images of the group handled together (shot <= 8).
+template <int CJ, int NS>
+__global__ __launch_bounds__(PF_THREADS) void proto_extend_fwd_kernel(
     const float* __restrict__ S, const float* __restrict__ cnt, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ Wl, const float* __restrict__ bl, const float* __restrict__ weight,
@@ -61,59 +69,39 @@ __global__ __launch_bounds__(PE_THREADS) void proto_extend_fwd_kernel(
     const float* __restrict__ weight_mask, int way, int shot, int K, float Pf,
     float* __restrict__ hidden, float* __restrict__ gate, float* __restrict__ pool, float* __restrict__ Wn) {
     constexpr int C = CJ * 64;
+    constexpr int STEPS = C / PF_ROWS, T = 3 * STEPS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xa = sm;                    // att     [shot][C]
-    float* xb = xa + shot * C;         // hidden  [shot][C]
-    float* xc = xb + shot * C;         // pool    [shot][C]
-    float* pbar = xc + shot * C;       // [C]
+    float* xa = sm;                    // layer input (att, hidden, mean pool)  [NS][C]
+    float* zb = xa + NS * C;           // layer output before bias             [NS][C]
+    float* sraw = zb + NS * C;         // S                                    [NS][C]
+    float* gmk = sraw + NS * C;        // gate mask                            [NS][C]
+    float* cden = gmk + NS * C;        // cnt + eps [NS]
     const int grp = blockIdx.x;
     const int n = grp / way, j = grp - n * way;
     const int64_t b0 = (int64_t)grp * shot;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wrow = wave * 4 + (lane >> 4), wcol = (lane & 15) * 4;
+    const int ns = shot;
 
-    // att = mean over all P positions of mask*F  (model/common.py:243)
-    for (int i = tid; i < shot * C; i += PE_THREADS) xa[i] = S[b0 * C + i] / Pf;
-    __syncthreads();
-    // hidden = relu(W1 att + b1)  (model/common.py:226-228)
-    dense_rows<CJ>(W1, b1, xa, shot, [&](int o, int s, float v) {
-        v = fmaxf(v, 0.f);
-        xb[s * C + o] = v;
-        hidden[(b0 + s) * C + o] = v;
-    });
-    __syncthreads();
-    // g = sigmoid(dropout(W2 hidden + b2)); pool = g*S/(cnt+eps)  (model/common.py:229-232,192-194)
-    dense_rows<CJ>(W2, b2, xb, shot, [&](int o, int s, float v) {
-        const int64_t idx = (b0 + s) * C + o;
-        if (gate_mask) v *= gate_mask[idx];
-        const float g = 1.f / (1.f + expf(-v));
-        gate[idx] = g;
-        const float pl = g * S[idx] / (cnt[b0 + s] + PE_EPS);
-        pool[idx] = pl;
-        xc[s * C + o] = pl;
-    });
-    __syncthreads();
-    // proto = Wl pool + bl, then mean over shot  (model/common.py:196,319)
-    {
-        float run = 0.f;
-        const float inv = (float)shot;
-        dense_rows<CJ>(Wl, bl, xc, shot, [&](int o, int s, float v) {
-            run = (s == 0) ? v : run + v;
-            if (s == shot - 1) pbar[o] = run / inv;
-        });
-    }
-    __syncthreads();
+    f32x4 ring[PF_DEPTH + 1][CJ];
+    auto issue = [&](int t, f32x4 (&dst)[CJ]) {
+        const float* W = (t < STEPS) ? W1 : (t < 2 * STEPS ? W2 : Wl);
+        const int it = t % STEPS;
+        const float* p = W + (int64_t)(it * PF_ROWS + wrow) * C + wcol;
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) dst[jj] = *reinterpret_cast<const f32x4*>(p + 64 * jj);
+    };
+    STAMP(0);
+#pragma unroll
+    for (int t = 0; t < PF_DEPTH; ++t)
+        if (t < T) issue(t, ring[t]);
 
-    // Wn[n] = dropout(weight); Wn[n, label_j] = pbar  (model/common.py:317-334)
+    // Wn[n] = dropout(weight) for the rows no way of this episode overwrites (model/common.py:317,326)
     const int64_t* lab = labels + (int64_t)n * way;
-    const int64_t mine = lab[j];
-    bool win = mine >= 0 && mine < K;
-    for (int jj = j + 1; jj < way; ++jj) win = win && (lab[jj] != mine);     // a later way overwrites
     float* Wn_n = Wn + (int64_t)n * K * C;
-    if (win)
-        for (int c = tid; c < C; c += PE_THREADS) Wn_n[mine * C + c] = pbar[c];
     if (j == 0) {
         const float* wm = weight_mask ? weight_mask + (int64_t)n * K * C : nullptr;
-        for (int idx = tid * 4; idx < K * C; idx += PE_THREADS * 4) {
+        for (int idx = tid * 4; idx < K * C; idx += PF_THREADS * 4) {
             const int k = idx / C;
             bool novel = false;
             for (int jj = 0; jj < way; ++jj) novel = novel || (lab[jj] == k);
@@ -126,75 +114,138 @@ __global__ __launch_bounds__(PE_THREADS) void proto_extend_fwd_kernel(
             *reinterpret_cast<f32x4*>(Wn_n + idx) = v;
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// Backward, stage A: per-group chain.  Transposed mat-vecs for up to 8 images
-// at a time (vin laid out [C][8] in LDS, zero padded).
-//   y[s][i] = sum_o W[o][i] * vin[o][s]
-// Each thread owns column i = tid % C for the row range of its split; partials
-// are combined through LDS.  Result handed to epi(i, s, y) by split 0.
-// ---------------------------------------------------------------------------
-template <typename Epi>
-__device__ __forceinline__ void dense_cols8(const float* __restrict__ W, const float* vin /*[C][8]*/,
-                                            float* red /*[nsplit][8][C]*/, int C, int ns, Epi epi) {
-    const int tid = threadIdx.x;
-    const int nsplit = PE_THREADS / C;            // C in {64,128,256,512}
-    const int i = tid % C, sp = tid / C;
-    const int rows = C / nsplit;
-    const int o0 = sp * rows;
-    float acc[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
-#pragma unroll 4
-    for (int o = o0; o < o0 + rows; ++o) {
-        const float wv = W[(int64_t)o * C + i];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vin + o * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(vin + o * 8 + 4);
-        acc[0] += wv * v0[0]; acc[1] += wv * v0[1]; acc[2] += wv * v0[2]; acc[3] += wv * v0[3];
-        acc[4] += wv * v1[0]; acc[5] += wv * v1[1]; acc[6] += wv * v1[2]; acc[7] += wv * v1[3];
+    // att = mean over all P positions of mask*F  (model/common.py:243); unused slots are zero
+    for (int i = tid; i < NS * C; i += PF_THREADS) {
+        const bool ok = i < ns * C;
+        const float sv = ok ? S[b0 * C + i] : 0.f;
+        sraw[i] = sv;
+        xa[i] = sv / Pf;
+        gmk[i] = (ok && gate_mask) ? gate_mask[b0 * C + i] : 1.f;
     }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) red[(sp * 8 + s) * C + i] = acc[s];
+    if (tid < NS) cden[tid] = (tid < ns ? cnt[b0 + tid] : 1.f) + PE_EPS;
     __syncthreads();
-    if (sp == 0) {
+    STAMP(1);
+
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s < ns) {
-                float t = 0.f;
-                for (int q = 0; q < nsplit; ++q) t += red[(q * 8 + s) * C + i];
-                epi(i, s, t);
+    for (int t = 0; t < T; ++t) {
+        if (t + PF_DEPTH < T) issue(t + PF_DEPTH, ring[(t + PF_DEPTH) & PF_DEPTH]);
+        const int layer = t / STEPS, it = t % STEPS;
+        if (layer < 2) layer_step<CJ, NS>(ring[t & PF_DEPTH], xa, zb, it);
+        else layer_step<CJ, 1>(ring[t & PF_DEPTH], xa, zb, it);
+        if (it == STEPS - 1) {
+            __syncthreads();
+            if (layer == 0) {
+                // hidden = relu(W1 att + b1)  (model/common.py:226-228)
+                for (int i = tid; i < NS * C; i += PF_THREADS) {
+                    const float v = fmaxf(zb[i] + b1[i % C], 0.f);
+                    xa[i] = v;
+                    if (i < ns * C) hidden[b0 * C + i] = v;
+                }
+                STAMP(2);
+            } else if (layer == 1) {
+                // g = sigmoid(dropout(W2 hidden + b2)); pool = g*S/(cnt+eps)  (model/common.py:229-232,192-194)
+                for (int i = tid; i < ns * C; i += PF_THREADS) {
+                    const int o = i % C, s = i / C;
+                    const float v = (zb[i] + b2[o]) * gmk[i];
+                    const float g = 1.f / (1.f + expf(-v));
+                    gate[b0 * C + i] = g;
+                    const float pl = g * sraw[i] / cden[s];
+                    pool[b0 * C + i] = pl;
+                    zb[i] = pl;
+                }
+                __syncthreads();
+                // mean_s (Wl pool_s + bl) = Wl (mean_s pool_s) + bl: one mat-vec per group (model/common.py:196,319)
+                for (int c = tid; c < C; c += PF_THREADS) {
+                    float tsum = 0.f;
+                    for (int s = 0; s < ns; ++s) tsum += zb[s * C + c];
+                    xa[c] = tsum / (float)shot;
+                }
+                STAMP(3);
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
+    STAMP(4);
+    // Wn[n, label_j] = prototype  (model/common.py:327-334); a later way overwrites an earlier one
+    const int64_t mine = lab[j];
+    bool win = mine >= 0 && mine < K;
+    for (int jj = j + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
+    if (win)
+        for (int c = tid; c < C; c += PF_THREADS) Wn_n[mine * C + c] = zb[c] + bl[c];
+    STAMP(5);
 }
 
-__global__ __launch_bounds__(PE_THREADS) void proto_extend_bwd_chain_kernel(
+// ---------------------------------------------------------------------------
+// Backward, stage A: per-group chain of three transposed mat-vecs for up to 8 images at a time
+// (vin laid out [C][8] in LDS, zero padded):   y[s][i] = sum_o W[o][i] * vin[o][s]
+// 512 threads: thread (i = tid % C, sp = tid / C) owns column i for R = C*C/512 consecutive rows,
+// taken in chunks of CH rows.  As in the forward kernel the three mat-vecs are one sequence of
+// chunks whose loads run through a 4-slot register ring three chunks ahead of the FMAs.
+// ---------------------------------------------------------------------------
+#define CH_THREADS 512
+
+template <int CH>
+__device__ __forceinline__ void cols_chunk(const float (&wr)[CH], const float* vin /*[C][8]*/, int o0, float (&acc)[8]) {
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8 + 4);
+        acc[0] += wr[t] * v0[0]; acc[1] += wr[t] * v0[1]; acc[2] += wr[t] * v0[2]; acc[3] += wr[t] * v0[3];
+        acc[4] += wr[t] * v1[0]; acc[5] += wr[t] * v1[1]; acc[6] += wr[t] * v1[2]; acc[7] += wr[t] * v1[3];
+    }
+}
+
+// sum of the splits' partial results for (column i, image s)
+__device__ __forceinline__ float cols_total(const float* red, int C, int i, int s) {
+    const int nsplit = CH_THREADS / C;
+    float t = 0.f;
+    for (int q = 0; q < nsplit; ++q) t += red[(q * 8 + s) * C + i];
+    return t;
+}
+
+template <int C, int CH>
+__global__ __launch_bounds__(CH_THREADS) void proto_extend_bwd_chain_kernel(
     const float* __restrict__ dWn_part, int n_part, const float* __restrict__ S,
     const float* __restrict__ cnt, const float* __restrict__ hidden, const float* __restrict__ gate,
     const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wl,
     const int64_t* __restrict__ labels, const float* __restrict__ gate_mask, int way, int shot, int K,
-    int C, float Pf, float* __restrict__ u1 /*dpre1 [B,C]*/, float* __restrict__ u2 /*dz [B,C]*/,
+    float Pf, float* __restrict__ u1 /*dpre1 [B,C]*/, float* __restrict__ u2 /*dz [B,C]*/,
     float* __restrict__ u3 /*dproto [B,C]*/, float* __restrict__ coef /*[B,C]*/) {
+    constexpr int R = C * C / CH_THREADS;        // rows per thread
+    constexpr int NCH = R / CH, T = 3 * NCH;     // chunks per mat-vec, chunks in all
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* vin = sm;                 // [C][8]
     float* red = vin + C * 8;        // [nsplit*8][C]  (nsplit*C = 512)
-    float* dpool = red + PE_THREADS * 8;   // [C]
+    float* dpool = red + CH_THREADS * 8;   // [C]
     const int grp = blockIdx.x;
     const int n = grp / way, j = grp - n * way;
     const int64_t b0 = (int64_t)grp * shot;
     const int tid = threadIdx.x;
+    const int ci = tid % C, sp = tid / C;
+    const int ns = shot;
+
+    float ring[4][CH];
+    auto issue = [&](int t, float (&dst)[CH]) {
+        const float* W = (t < NCH) ? Wl : (t < 2 * NCH ? W2 : W1);
+        const int ch = t % NCH;
+        const float* p = W + (int64_t)(sp * R + ch * CH) * C + ci;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) dst[q] = p[(int64_t)q * C];
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < T) issue(t, ring[t]);
 
     // dproto[s] = dWn[n, label_j] / shot for every shot (mean backward), if this way owns the row
     const int64_t* lab = labels + (int64_t)n * way;
     const int64_t mine = lab[j];
     bool win = mine >= 0 && mine < K;
     for (int jj = j + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
-    for (int c = tid; c < C; c += PE_THREADS) {
+    for (int c = tid; c < C; c += CH_THREADS) {
         float t = 0.f;
         if (win) {
             const float* src = dWn_part + (((int64_t)n * n_part) * K + mine) * C + c;
+#pragma unroll 8
             for (int q = 0; q < n_part; ++q) t += src[(int64_t)q * K * C];
         }
         t /= (float)shot;
@@ -203,45 +254,77 @@ __global__ __launch_bounds__(PE_THREADS) void proto_extend_bwd_chain_kernel(
         for (int s = 0; s < shot; ++s) u3[(b0 + s) * C + c] = t;
     }
     __syncthreads();
-    // dpool[i] = sum_o Wl[o][i] * dproto[o]   (identical for every shot of the group)
-    dense_cols8(Wl, vin, red, C, 1, [&](int i, int, float v) { dpool[i] = v; });
 
-    for (int s0 = 0; s0 < shot; s0 += 8) {
-        const int ns = min(8, shot - s0);
-        // dz = dpool * S/(cnt+eps) * g(1-g) * gate_mask      (pool = g*S/(cnt+eps))
-        for (int idx = tid; idx < C * 8; idx += PE_THREADS) {
-            const int c = idx >> 3, s = idx & 7;
-            float dz = 0.f;
-            if (s < ns) {
-                const int64_t gi = (b0 + s0 + s) * C + c;
-                const float g = gate[gi];
-                const float den = cnt[b0 + s0 + s] + PE_EPS;
-                dz = dpool[c] * S[gi] / den * g * (1.f - g);
-                if (gate_mask) dz *= gate_mask[gi];
-                u2[gi] = dz;
+    float acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (t + 3 < T) issue(t + 3, ring[(t + 3) & 3]);
+        const int mv = t / NCH, ch = t % NCH;
+        cols_chunk<CH>(ring[t & 3], vin, sp * R + ch * CH, acc);
+        if (ch == NCH - 1) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { red[(sp * 8 + s) * C + ci] = acc[s]; acc[s] = 0.f; }
+            __syncthreads();
+            if (mv == 0) {
+                // dpool[i] = sum_o Wl[o][i] * dproto[o]   (identical for every shot of the group)
+                for (int i = tid; i < C; i += CH_THREADS) dpool[i] = cols_total(red, C, i, 0);
+                __syncthreads();
+                // dz = dpool * S/(cnt+eps) * g(1-g) * gate_mask      (pool = g*S/(cnt+eps))
+                for (int idx = tid; idx < C * 8; idx += CH_THREADS) {
+                    const int c = idx >> 3, s = idx & 7;
+                    float dz = 0.f;
+                    if (s < ns) {
+                        const int64_t gi = (b0 + s) * C + c;
+                        const float g = gate[gi];
+                        const float den = cnt[b0 + s] + PE_EPS;
+                        dz = dpool[c] * S[gi] / den * g * (1.f - g);
+                        if (gate_mask) dz *= gate_mask[gi];
+                        u2[gi] = dz;
+                    }
+                    vin[idx] = dz;
+                }
+            } else if (mv == 1) {
+                // dhidden = W2^T dz ; dpre1 = dhidden * (hidden > 0)
+                for (int idx = tid; idx < C * 8; idx += CH_THREADS) {
+                    const int c = idx >> 3, s = idx & 7;
+                    float d = 0.f;
+                    if (s < ns) {
+                        const int64_t gi = (b0 + s) * C + c;
+                        d = hidden[gi] > 0.f ? cols_total(red, C, c, s) : 0.f;
+                        u1[gi] = d;
+                    }
+                    vin[idx] = d;
+                }
+            } else {
+                // datt = W1^T dpre1 ; coef = dpool*g/(cnt+eps) + datt/P
+                for (int idx = tid; idx < C * ns; idx += CH_THREADS) {
+                    const int s = idx / C, c = idx - s * C;
+                    const int64_t gi = (b0 + s) * C + c;
+                    const float den = cnt[b0 + s] + PE_EPS;
+                    coef[gi] = dpool[c] * gate[gi] / den + cols_total(red, C, c, s) / Pf;
+                }
             }
-            vin[idx] = dz;
+            __syncthreads();
         }
-        __syncthreads();
-        // dhidden = W2^T dz ; dpre1 = dhidden * (hidden > 0)
-        dense_cols8(W2, vin, red, C, ns, [&](int i, int s, float v) {
-            const int64_t gi = (b0 + s0 + s) * C + i;
-            const float d = hidden[gi] > 0.f ? v : 0.f;
-            u1[gi] = d;
-            // stash for the next mat-vec (vin is free: all reads finished before the reduce barrier)
-            vin[i * 8 + s] = d;
-        });
-        // zero the padding columns of vin (s >= ns) -- they still hold dz of this chunk
-        for (int idx = tid; idx < C * 8; idx += PE_THREADS)
-            if ((idx & 7) >= ns) vin[idx] = 0.f;
-        __syncthreads();
-        // datt = W1^T dpre1 ; coef = dpool*g/(cnt+eps) + datt/P
-        dense_cols8(W1, vin, red, C, ns, [&](int i, int s, float v) {
-            const int64_t gi = (b0 + s0 + s) * C + i;
-            const float den = cnt[b0 + s0 + s] + PE_EPS;
-            coef[gi] = dpool[i] * gate[gi] / den + v / Pf;
-        });
     }
+}
+
+// dWn[n,k,c] = sum over position tiles of the partial slabs K3b wrote (fixed order: deterministic)
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int n_part, int64_t per_n,
+                                                          float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= per_n) return;
+    const float* src = part + (int64_t)n * n_part * per_n + i4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 9
+    for (int q = 0; q < n_part; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)q * per_n);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(out + (int64_t)n * per_n + i4) = a;
 }
 
 // ---------------------------------------------------------------------------
@@ -260,21 +343,45 @@ __global__ __launch_bounds__(256) void proto_extend_bwd_params_kernel(
     const int which = blockIdx.y;
     const int tid = threadIdx.x;
     if (which == 3) {
+        // dweight[k,c] = sum over (n, tile) of the partial slabs, novel rows and dropped entries excluded.
+        // The 256 threads are C/4 float4 columns x (1024/C) groups that split the (n, tile) pairs.
+        __shared__ f32x4 redw[256];
         const int k = blockIdx.x;
         if (k >= K) return;
-        for (int c = tid; c < C; c += 256) {
-            float t = 0.f;
+        const int c4n = C >> 2;                 // float4 columns
+        const int ngrp = 256 / c4n;             // C=256 -> 4 groups
+        const int c4 = tid % c4n, grp = tid / c4n;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (grp < ngrp) {
+            const int pairs = N * n_part;
             for (int n = 0; n < N; ++n) {
                 bool novel = false;
                 for (int jj = 0; jj < way; ++jj) novel = novel || (labels[(int64_t)n * way + jj] == k);
                 if (novel) continue;
-                const float* src = dWn_part + (((int64_t)n * n_part) * K + k) * C + c;
-                float a = 0.f;
-                for (int q = 0; q < n_part; ++q) a += src[(int64_t)q * K * C];
-                if (weight_mask) a *= weight_mask[((int64_t)n * K + k) * C + c];
-                t += a;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                const float* src = dWn_part + (((int64_t)n * n_part) * K + k) * C + c4 * 4;
+#pragma unroll 8
+                for (int q = grp; q < n_part; q += ngrp) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)q * K * C);
+                    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+                }
+                if (weight_mask) {
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(weight_mask + ((int64_t)n * K + k) * C + c4 * 4);
+                    a[0] *= m[0]; a[1] *= m[1]; a[2] *= m[2]; a[3] *= m[3];
+                }
+                t[0] += a[0]; t[1] += a[1]; t[2] += a[2]; t[3] += a[3];
             }
-            dweight[(int64_t)k * C + c] = t;
+            (void)pairs;
+        }
+        redw[tid] = t;
+        __syncthreads();
+        if (tid < c4n) {
+            f32x4 r = redw[tid];
+            for (int g2 = 1; g2 < ngrp; ++g2) {
+                const f32x4 v = redw[g2 * c4n + tid];
+                r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3];
+            }
+            *reinterpret_cast<f32x4*>(dweight + (int64_t)k * C + tid * 4) = r;
         }
         return;
     }
@@ -289,7 +396,7 @@ __global__ __launch_bounds__(256) void proto_extend_bwd_params_kernel(
         float acc[WG_ROWS];
 #pragma unroll
         for (int r = 0; r < WG_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int b = 0; b < B; ++b) {
             const float v = V[(int64_t)b * C + i];
 #pragma unroll
@@ -309,7 +416,7 @@ __global__ __launch_bounds__(256) void proto_extend_bwd_params_kernel(
 // C ABI
 // ---------------------------------------------------------------------------
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
-static inline bool c_ok(int64_t C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+static inline bool c_ok(int64_t C) { return C == 64 || C == 128 || C == 256; }
 
 extern "C" int denet_proto_extend_fwd(const float* S, const float* cnt, const float* W1, const float* b1,
                                       const float* W2, const float* b2, const float* Wl, const float* bl,
@@ -321,27 +428,34 @@ extern "C" int denet_proto_extend_fwd(const float* S, const float* cnt, const fl
         !pool || !Wn)
         return DENET_E_BADARG;
     if (!pos(N) || !pos(way) || !pos(shot) || !pos(K) || !pos(C) || !pos(P)) return DENET_E_BADARG;
-    if (!c_ok(C) || K > 128) return DENET_E_UNSUPPORTED;
-    const size_t lds = (size_t)(3 * shot + 1) * C * 4;
-    if (lds > 64 * 1024) return DENET_E_UNSUPPORTED;
-    dim3 grid((unsigned)(N * way)), block(PE_THREADS);
+    if (!c_ok(C) || K > 128 || shot > 8) return DENET_E_UNSUPPORTED;
+    dim3 grid((unsigned)(N * way)), block(PF_THREADS);
     hipStream_t st = (hipStream_t)stream;
-#define PE_LAUNCH(CJ)                                                                                      \
-    hipLaunchKernelGGL(proto_extend_fwd_kernel<CJ>, grid, block, lds, st, S, cnt, W1, b1, W2, b2, Wl, bl,   \
-                       weight, labels, gate_mask, weight_mask, (int)way, (int)shot, (int)K, (float)P,       \
-                       hidden, gate, pool, Wn)
+#define PE_LAUNCH2(CJ, NS)                                                                                  \
+    hipLaunchKernelGGL((proto_extend_fwd_kernel<CJ, NS>), grid, block, (size_t)(4 * NS * C + NS + 4) * 4, st, S, \
+                       cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, (int)way, (int)shot, \
+                       (int)K, (float)P, hidden, gate, pool, Wn)
+#define PE_LAUNCH(CJ)                                  \
+    if (shot == 1) PE_LAUNCH2(CJ, 1);                  \
+    else if (shot <= 3) PE_LAUNCH2(CJ, 3);             \
+    else if (shot <= 5) PE_LAUNCH2(CJ, 5);             \
+    else PE_LAUNCH2(CJ, 8)
     switch (C) {
         case 64: PE_LAUNCH(1); break;
         case 128: PE_LAUNCH(2); break;
         case 256: PE_LAUNCH(4); break;
-        default: PE_LAUNCH(8); break;
+        default: return DENET_E_UNSUPPORTED;
     }
+#undef PE_LAUNCH2
 #undef PE_LAUNCH
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
 
-extern "C" int64_t denet_proto_extend_bwd_workspace(int64_t B, int64_t C) { return 3 * B * C * 4; }
+extern "C" int64_t denet_proto_extend_bwd_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C) {
+    if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0) return DENET_E_BADARG;
+    return (3 * N * way * shot * C + N * K * C) * 4;
+}
 
 extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, const float* S, const float* cnt,
                                       const float* hidden, const float* gate, const float* pool,
@@ -355,17 +469,35 @@ extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, con
         return DENET_E_BADARG;
     if (!pos(N) || !pos(way) || !pos(shot) || !pos(K) || !pos(C) || !pos(P) || !pos(n_part))
         return DENET_E_BADARG;
-    if (!c_ok(C) || K > 128) return DENET_E_UNSUPPORTED;
+    if (!c_ok(C) || K > 128 || shot > 8) return DENET_E_UNSUPPORTED;
     const int64_t B = N * way * shot;
-    if (ws_bytes < denet_proto_extend_bwd_workspace(B, C)) return DENET_E_WORKSPACE;
+    if (ws_bytes < denet_proto_extend_bwd_workspace(N, way, shot, K, C)) return DENET_E_WORKSPACE;
+    if (N > 65535) return DENET_E_UNSUPPORTED;
     float* u1 = (float*)ws;
     float* u2 = u1 + B * C;
     float* u3 = u2 + B * C;
+    float* dWn = u3 + B * C;                      // [N,K,C] tile-reduced
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(C * 8 + PE_THREADS * 8 + C) * 4;
-    hipLaunchKernelGGL(proto_extend_bwd_chain_kernel, dim3((unsigned)(N * way)), dim3(PE_THREADS), lds, st,
-                       dWn_part, (int)n_part, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, (int)way,
-                       (int)shot, (int)K, (int)C, (float)P, u1, u2, u3, coef);
+    if (n_part > 1) {
+        const int64_t per_n = K * C;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((per_n / 4 + 255) / 256), (unsigned)N), dim3(256), 0,
+                           st, dWn_part, (int)n_part, per_n, dWn);
+        DENET_CHECK_LAUNCH();
+        dWn_part = dWn;
+        n_part = 1;
+    }
+    const size_t lds = (size_t)(C * 8 + CH_THREADS * 8 + C) * 4;
+#define CH_LAUNCH(CC, CHK)                                                                                   \
+    hipLaunchKernelGGL((proto_extend_bwd_chain_kernel<CC, CHK>), dim3((unsigned)(N * way)), dim3(CH_THREADS),  \
+                       lds, st, dWn_part, (int)n_part, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask,   \
+                       (int)way, (int)shot, (int)K, (float)P, u1, u2, u3, coef)
+    switch (C) {
+        case 64: CH_LAUNCH(64, 8); break;
+        case 128: CH_LAUNCH(128, 16); break;
+        case 256: CH_LAUNCH(256, 16); break;
+        default: return DENET_E_UNSUPPORTED;
+    }
+#undef CH_LAUNCH
     DENET_CHECK_LAUNCH();
     const unsigned gx = (unsigned)((C / WG_ROWS) > K ? (C / WG_ROWS) : K);
     hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, st, u1, u2, u3, S, hidden,

@@ -24,7 +24,9 @@ class HeadStepEngine:
         self.device = device
         self.feat_dtype = feat_dtype
         f32 = dict(dtype=torch.float32, device=device)
-        self.ws_bytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w)
+        self.ws_bytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
+        if self.ws_bytes < 0:
+            raise _lib.DenetHipError(_lib.strerror(self.ws_bytes))
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.logits_full = torch.empty(N, K, h, w, **f32)
         self.logits_binary = torch.empty(N * way, 2, h, w, **f32)
@@ -65,6 +67,6 @@ class HeadStepEngine:
         g = self.grads
         call("denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
              params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
-             N, way, shot, K, C, h, w, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
+             N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
              g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
              g["map.linear.bias"], self.ws, self.ws_bytes, self._probe)

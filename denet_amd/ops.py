@@ -81,7 +81,7 @@ def proto_extend_bwd(dWn_part, n_part, S, cnt, saved, params, labels, N, way, sh
     db1, db2, dbl = (_f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev))
     dweight = _f32(K, C, device=dev)
     coef = _f32(B, C, device=dev)
-    nbytes = query("denet_proto_extend_bwd_workspace", B, C)
+    nbytes = query("denet_proto_extend_bwd_workspace", N, way, shot, K, C)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     call("denet_proto_extend_bwd", dWn_part, n_part, S, cnt, hidden, gate, pool, W1, W2, Wl, labels,
          gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl, dweight, coef, ws, nbytes)
@@ -133,14 +133,17 @@ def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False):
     Y = _as_i64(Yq_full).contiguous().reshape(N, *Yq_full.shape[-2:])
     H, W = Y.shape[-2:]
     dev = logits.device
-    part = _f32(N, h, 2, device=dev)
+    parts = query("denet_upsample_loss_parts", K, h, w, H, W, 1 if grad else 0)
+    if parts < 0:
+        raise _lib.DenetHipError(f"denet_upsample_loss_parts: {_lib.strerror(parts)}")
+    part = _f32(N, parts, 2, device=dev)
     da = torch.empty_like(logits) if grad else None
     db = torch.empty_like(logits) if grad else None
     call("denet_upsample_wce_fwd", logits, Y, wgt, N, K, h, w, H, W, part, da, db)
     out = _f32(2, device=dev)
     per = _f32(N, device=dev)
     scale = _f32(N, device=dev)
-    call("denet_loss_finalize", part, None, N, 0, h, 1 if pooled else 0, out, per, scale)
+    call("denet_loss_finalize", part, None, N, 0, parts, 0, 1 if pooled else 0, out, per, scale)
     return out[0], per, scale, da, db
 
 
@@ -150,10 +153,13 @@ def upsample_focal(logits_binary, Yq, alpha=0.25, gamma=2.0):
     assert two == 2
     Y = _as_i64(Yq).contiguous().reshape(NB, *Yq.shape[-2:])
     H, W = Y.shape[-2:]
-    part = _f32(NB, h, 2, device=lb.device)
+    parts = query("denet_upsample_loss_parts", 2, h, w, H, W, 0)
+    if parts < 0:
+        raise _lib.DenetHipError(f"denet_upsample_loss_parts: {_lib.strerror(parts)}")
+    part = _f32(NB, parts, 2, device=lb.device)
     call("denet_upsample_focal_fwd", lb, Y, NB, h, w, H, W, alpha, gamma, part)
     out = _f32(2, device=lb.device)
-    call("denet_loss_finalize", None, part, 0, NB, h, 0, out, None, None)
+    call("denet_loss_finalize", None, part, 0, NB, 0, parts, 0, out, None, None)
     return out[1]
 
 
@@ -318,7 +324,9 @@ class HeadStepFunction(torch.autograd.Function):
         Yq = _as_i64(Yq).contiguous() if Yq is not None else None
         Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
         need = any(t.requires_grad for t in (Fq, Fs) + params)
-        nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w)
+        nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
+        if nbytes < 0:
+            raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(nbytes)}")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         logits = _f32(N, K, h, w, device=dev)
         binl = _f32(N * way, 2, h, w, device=dev)
@@ -326,7 +334,7 @@ class HeadStepFunction(torch.autograd.Function):
         call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *params,
              gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
              ws, nbytes, None)
-        ctx.dims = (N, way, shot, K, C, h, w)
+        ctx.dims = (N, way, shot, K, C, h, w, H, W)
         ctx.ws = ws
         ctx.fs_shape = Fs.shape
         ctx.save_for_backward(Fq, labels, params[1], params[3], params[5],
@@ -341,7 +349,7 @@ class HeadStepFunction(torch.autograd.Function):
     def backward(ctx, g_k, g_p, g_l, g_b):
         if g_k is None:
             return (None,) * 16
-        N, way, shot, K, C, h, w = ctx.dims
+        N, way, shot, K, C, h, w, H, W = ctx.dims
         sv = list(ctx.saved_tensors)
         Fq, labels, W1, W2, Wl = sv[:5]
         rest = sv[5:]
@@ -355,5 +363,6 @@ class HeadStepFunction(torch.autograd.Function):
         db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
         g = g_k.contiguous().float().reshape(1)
         call("denet_head_step_bwd", Fq, feat_code(Fq), labels, W1, W2, Wl, gate_mask, weight_mask, g,
-             N, way, shot, K, C, h, w, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws, ctx.ws.numel(), None)
+             N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws,
+             ctx.ws.numel(), None)
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7

@@ -18,7 +18,8 @@
  *      masks     [B, H, W]   int64
  *      logits    [N, K, h, w] fp32
  *  - B = N*way*shot support images, P = h*w feature positions.
- *  - C must be a multiple of 64 and <= 512; K <= 128.
+ *  - C (feature depth) must be 64 or 256 (the reference fixes 256: model/head/denet.py:27,47;
+ *    64 exists for small test fixtures); K <= 128.
  */
 #ifndef DENET_HIP_H
 #define DENET_HIP_H
@@ -85,8 +86,8 @@ int denet_proto_extend_fwd(const float* S, const float* cnt,
  * `n_part` partial slabs [N,n_part,K,C] that are summed here (K3b writes one
  * slab per position tile).  Outputs: gradients of the seven parameters and
  * coef [B,C] for denet_masked_sum_bwd.  ws: workspace of
- * denet_proto_extend_bwd_workspace(B,C) bytes. */
-int64_t denet_proto_extend_bwd_workspace(int64_t B, int64_t C);
+ * denet_proto_extend_bwd_workspace(N,way,shot,K,C) bytes. */
+int64_t denet_proto_extend_bwd_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C);
 int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part,
                            const float* S, const float* cnt,
                            const float* hidden, const float* gate, const float* pool,
@@ -142,22 +143,24 @@ int denet_classify_bwd(const void* Fq, int feat_dtype, const float* Wn,
  * upper / the lower bilinear tap), to be combined as scale[n]*(a+b) with
  * scale[n] = 1/(N*den[n])  (loss_k is a mean over episodes of per-episode
  * weighted means).
- * Focal part (optional, logits_binary != NULL): Yq [NB,H,W], NB = N*way.
- * part: workspace [N*h + NB*h, 4] floats of per-band partial sums.
+ * Focal: Yq [NB,H,W], NB = N*way.
+ * part: [N, parts, 2] floats of per-block partial (num, den) sums, with
+ * parts = denet_upsample_loss_parts(K, h, w, H, W, with_grad) (K = 2, with_grad = 0 for focal).
  * denet_loss_finalize reduces them: out[0]=loss_k, out[1]=loss_p.
  *   pooled = 0: loss_k = mean_n num[n]/den[n], scale[n] = 1/(N*den[n])   (trainer/utils.py:270-277)
  *   pooled = 1: loss_k = sum num / sum den,    scale[n] = 1/sum den      (loss/losses.py:39-44 on a batch)
  * denet_combine_slabs: out = gmul * scale[n] * (a + b): the dense gradient
  * w.r.t. the logits for callers that need it as a tensor.
  */
+int64_t denet_upsample_loss_parts(int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, int with_grad);
 int denet_upsample_wce_fwd(const float* logits, const int64_t* Yq_full, const float* wgt /*[N,K] or NULL*/,
                            int64_t N, int64_t K, int64_t h, int64_t w, int64_t H, int64_t W,
-                           float* part /*[N,h,2]*/, float* dlog_a, float* dlog_b, void* stream);
+                           float* part /*[N,parts,2]*/, float* dlog_a, float* dlog_b, void* stream);
 int denet_upsample_focal_fwd(const float* logits_binary, const int64_t* Yq,
                              int64_t NB, int64_t h, int64_t w, int64_t H, int64_t W,
-                             float alpha, float gamma, float* part /*[NB,h,2]*/, void* stream);
-int denet_loss_finalize(const float* part_k, const float* part_p, int64_t N, int64_t NB, int64_t h,
-                        int pooled, float* out /*[2]*/, float* per_episode /*[N] or NULL*/,
+                             float alpha, float gamma, float* part /*[NB,parts,2]*/, void* stream);
+int denet_loss_finalize(const float* part_k, const float* part_p, int64_t N, int64_t NB,
+                        int64_t parts_k, int64_t parts_p, int pooled, float* out /*[2]*/, float* per_episode /*[N] or NULL*/,
                         float* scale /*[N] or NULL*/, void* stream);
 int denet_combine_slabs(const float* a, const float* b /*or NULL*/, const float* scale /*[N] or NULL*/,
                         const float* gmul /*device scalar or NULL*/, int64_t N, int64_t per /*K*h*w*/,
@@ -217,7 +220,7 @@ typedef struct denet_probe {
 } denet_probe_t;
 
 int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
-                                  int64_t h, int64_t w);
+                                  int64_t h, int64_t w, int64_t H, int64_t W);
 int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
                         const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
                         const float* wgt, const float* weight, const float* W1, const float* b1,
@@ -231,7 +234,7 @@ int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
                         const float* W1, const float* W2, const float* Wl,
                         const float* gate_mask, const float* weight_mask, const float* grad_loss_k,
                         int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
-                        void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
+                        int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
                         float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes,
                         const denet_probe_t* probe, void* stream);
 

@@ -1,0 +1,32 @@
+#define DENET_STAMPS 1
+#include "../../denet_amd/csrc/classify.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int main() {
+    const int N = 8, way = 1, K = 21, C = 256, P = 1681;
+    float *Fq, *Wn, *logits, *bin; int64_t* labels;
+    CK(hipMalloc(&Fq, (size_t)N * C * P * 4)); CK(hipMalloc(&Wn, N * K * C * 4)); CK(hipMalloc(&logits, N * K * P * 4));
+    CK(hipMalloc(&bin, N * 2 * P * 4)); CK(hipMalloc(&labels, N * 8));
+    CK(hipMemset(Fq, 0, (size_t)N * C * P * 4)); CK(hipMemset(Wn, 0, N * K * C * 4));
+    std::vector<int64_t> l(N, 3); CK(hipMemcpy(labels, l.data(), N * 8, hipMemcpyHostToDevice));
+    unsigned long long* d_st; CK(hipMalloc(&d_st, 64 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    float* junk; CK(hipMalloc(&junk, 512u << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 4; ++rep) {
+        if (rep < 2) CK(hipMemset(junk, rep, 512u << 20));
+        CK(hipMemset(d_st, 0, 64 * 8));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        int rc = denet_classify_fwd(Fq, DENET_F32, Wn, labels, N, way, K, C, P, 1, logits, bin, nullptr);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long st[64]; CK(hipMemcpy(st, d_st, 64 * 8, hipMemcpyDeviceToHost));
+        printf("classify_fwd rc=%d %s total %.1f us; block0 stamps(ns):", rc, rep < 2 ? "cold" : "warm", ms * 1e3);
+        for (int i = 1; i < 8 && st[i]; ++i) printf(" %llu", (st[i] - st[0]) * 10);
+        printf("\n");
+    }
+    return 0;
+}

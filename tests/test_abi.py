@@ -35,9 +35,10 @@ def test_version_and_strerror():
 def test_workspace_queries_are_pure_host_calls():
     from denet_amd import _lib
     assert _lib.query("denet_classify_bwd_parts", 1681) == 27
-    assert _lib.query("denet_proto_extend_bwd_workspace", 40, 256) == 3 * 40 * 256 * 4
-    assert _lib.query("denet_head_step_workspace", 8, 1, 5, 21, 256, 41, 41) > 0
-    assert _lib.query("denet_head_step_workspace", 0, 1, 5, 21, 256, 41, 41) < 0
+    assert _lib.query("denet_proto_extend_bwd_workspace", 8, 1, 5, 21, 256) == (3 * 40 * 256 + 8 * 21 * 256) * 4
+    assert _lib.query("denet_head_step_workspace", 8, 1, 5, 21, 256, 41, 41, 321, 321) > 0
+    assert _lib.query("denet_head_step_workspace", 0, 1, 5, 21, 256, 41, 41, 321, 321) < 0
+    assert _lib.query("denet_upsample_loss_parts", 21, 41, 41, 321, 321, 1) % 41 == 0
 
 
 def test_cpu_tensor_is_rejected_loudly():
