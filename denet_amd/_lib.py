@@ -22,11 +22,14 @@ _SIGS = {
     "denet_mask_resize": "plllllpp",
     "denet_masked_sum_fwd": "piplllp",
     "denet_masked_sum_bwd": "pplllpi",
-    "denet_proto_extend_fwd": "pppppppppppp" "llllll" "pppp",
+    "denet_proto_extend_fwd": "pppppppppppp" "llllll" "ppppp",
     "denet_proto_extend_bwd": "pl" "ppppp" "ppp" "ppp" "llllll" "pppppppp" "pl",
     "denet_classify_fwd": "pipp" "lllll" "i" "pp",
     "denet_classify_shared_fwd": "pip" "llll" "p",
     "denet_classify_bwd": "pip" "pppp" "llll" "pp",
+    "denet_binary_logits": "pp" "llll" "i" "p",
+    "denet_batch_mean": "p" "ll" "p",
+    "denet_sum_parts": "p" "lll" "p",
     "denet_upsample_wce_fwd": "ppp" "llllll" "ppp",
     "denet_upsample_focal_fwd": "pp" "lllll" "ff" "p",
     "denet_loss_finalize": "pp" "llll" "i" "ppp",

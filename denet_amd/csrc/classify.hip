@@ -354,6 +354,41 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// K3e stand-alone: get_binary_logits on an existing logits tensor (utils/operations.py:313-338)
+// and the batch mean of extended weights for mode='deploy' (model/common.py:369-372).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void binary_logits_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ labels, int way, int K,
+                                                           int P, int base, float* __restrict__ bin) {
+    const int nj = blockIdx.y, n = nj / way;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int64_t lab = labels[nj];
+    const float* src = logits + (int64_t)n * K * P + p;
+    float fg = 0.f, bg;
+    if (lab >= 0 && lab < K) fg = src[(int64_t)lab * P];
+    if (base) {
+        bg = -INFINITY;
+        for (int k = 0; k < K; ++k)
+            if (k != lab) bg = fmaxf(bg, src[(int64_t)k * P]);
+    } else {
+        bg = src[0];
+    }
+    float* dst = bin + ((int64_t)nj * 2) * P + p;
+    dst[0] = bg;
+    dst[P] = fg;
+}
+
+__global__ __launch_bounds__(256) void batch_mean_kernel(const float* __restrict__ x, int N, int64_t per,
+                                                        float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += x[(int64_t)n * per + i];
+    out[i] = t / (float)N;
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
@@ -464,4 +499,24 @@ extern "C" int denet_classify_bwd(const void* Fq, int feat_dtype, const float* W
         return launch_classify_bwd<unsigned short>((const unsigned short*)Fq, Wn, dlog_a, dlog_b, scale, gmul, N, K, C, P,
                                                    (unsigned short*)dFq, dWn_part, st);
     return DENET_E_UNSUPPORTED;
+}
+
+extern "C" int denet_binary_logits(const float* logits, const int64_t* labels, int64_t N, int64_t way, int64_t K,
+                                   int64_t P, int base, float* logits_binary, void* stream) {
+    if (!logits || !labels || !logits_binary) return DENET_E_BADARG;
+    if (!pos(N) || !pos(way) || !pos(K) || !pos(P)) return DENET_E_BADARG;
+    if (N * way > 65535) return DENET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(binary_logits_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(N * way)), dim3(256), 0,
+                       (hipStream_t)stream, logits, labels, (int)way, (int)K, (int)P, base, logits_binary);
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+extern "C" int denet_batch_mean(const float* x, int64_t N, int64_t per, float* out, void* stream) {
+    if (!x || !out) return DENET_E_BADARG;
+    if (!pos(N) || !pos(per)) return DENET_E_BADARG;
+    hipLaunchKernelGGL(batch_mean_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (int)N, per, out);
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
 }

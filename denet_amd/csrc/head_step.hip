@@ -90,7 +90,7 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
     PROBED(DENET_K_MASKED_SUM_FWD, denet_masked_sum_fwd(Fs, feat_dtype, s.mask, B, C, P, s.S, stream));
     PROBED(DENET_K_PROTO_EXTEND_FWD,
            denet_proto_extend_fwd(s.S, s.cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, N, way,
-                                  shot, K, C, P, s.hidden, s.gate, s.pool, s.Wn, stream));
+                                  shot, K, C, P, s.hidden, s.gate, s.pool, s.Wn, nullptr, stream));
     PROBED(DENET_K_CLASSIFY_FWD,
            denet_classify_fwd(Fq, feat_dtype, s.Wn, labels, N, way, K, C, P, 1, logits_full, logits_binary, stream));
     if (Yq_full) {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(PF_THREADS) void proto_extend_fwd_kernel(
     const float* __restrict__ Wl, const float* __restrict__ bl, const float* __restrict__ weight,
     const int64_t* __restrict__ labels, const float* __restrict__ gate_mask,
     const float* __restrict__ weight_mask, int way, int shot, int K, float Pf,
-    float* __restrict__ hidden, float* __restrict__ gate, float* __restrict__ pool, float* __restrict__ Wn) {
+    float* __restrict__ hidden, float* __restrict__ gate, float* __restrict__ pool, float* __restrict__ Wn,
+    float* __restrict__ proto) {
     constexpr int C = CJ * 64;
     constexpr int STEPS = C / PF_ROWS, T = 3 * STEPS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(PF_THREADS) void proto_extend_fwd_kernel(
     for (int jj = j + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
     if (win)
         for (int c = tid; c < C; c += PF_THREADS) Wn_n[mine * C + c] = zb[c] + bl[c];
+    if (proto)
+        for (int c = tid; c < C; c += PF_THREADS) proto[(int64_t)grp * C + c] = zb[c] + bl[c];
     STAMP(5);
 }
 
@@ -416,14 +419,14 @@ __global__ __launch_bounds__(256) void proto_extend_bwd_params_kernel(
 // C ABI
 // ---------------------------------------------------------------------------
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
-static inline bool c_ok(int64_t C) { return C == 64 || C == 128 || C == 256; }
+static inline bool c_ok(int64_t C) { return C == 64 || C == 256; }
 
 extern "C" int denet_proto_extend_fwd(const float* S, const float* cnt, const float* W1, const float* b1,
                                       const float* W2, const float* b2, const float* Wl, const float* bl,
                                       const float* weight, const int64_t* labels, const float* gate_mask,
                                       const float* weight_mask, int64_t N, int64_t way, int64_t shot,
                                       int64_t K, int64_t C, int64_t P, float* hidden, float* gate,
-                                      float* pool, float* Wn, void* stream) {
+                                      float* pool, float* Wn, float* proto, void* stream) {
     if (!S || !cnt || !W1 || !b1 || !W2 || !b2 || !Wl || !bl || !weight || !labels || !hidden || !gate ||
         !pool || !Wn)
         return DENET_E_BADARG;
@@ -434,7 +437,7 @@ extern "C" int denet_proto_extend_fwd(const float* S, const float* cnt, const fl
 #define PE_LAUNCH2(CJ, NS)                                                                                  \
     hipLaunchKernelGGL((proto_extend_fwd_kernel<CJ, NS>), grid, block, (size_t)(4 * NS * C + NS + 4) * 4, st, S, \
                        cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, (int)way, (int)shot, \
-                       (int)K, (float)P, hidden, gate, pool, Wn)
+                       (int)K, (float)P, hidden, gate, pool, Wn, proto)
 #define PE_LAUNCH(CJ)                                  \
     if (shot == 1) PE_LAUNCH2(CJ, 1);                  \
     else if (shot <= 3) PE_LAUNCH2(CJ, 3);             \
@@ -503,6 +506,19 @@ extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, con
     hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, st, u1, u2, u3, S, hidden,
                        pool, dWn_part, (int)n_part, labels, weight_mask, (int)N, (int)way, (int)B, (int)K,
                        (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight);
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+// dWn[n] = sum over position tiles of the slabs K3b wrote, as a tensor (the gradient of
+// WeightEstimator.infer w.r.t. its `weight` argument when extend and infer are called apart).
+extern "C" int denet_sum_parts(const float* part, int64_t N, int64_t n_part, int64_t per_n, float* out,
+                               void* stream) {
+    if (!part || !out) return DENET_E_BADARG;
+    if (!pos(N) || !pos(n_part) || !pos(per_n)) return DENET_E_BADARG;
+    if (N > 65535 || (per_n & 3)) return DENET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((per_n / 4 + 255) / 256), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, part, (int)n_part, per_n, out);
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }

@@ -58,15 +58,15 @@ def masked_sum_bwd(mask, coef, shape, dtype):
 # --------------------------------------------------------------------------
 # K2
 # --------------------------------------------------------------------------
-def proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask=None, weight_mask=None):
-    """-> (Wn [N,K,C], saved (hidden, gate, pool))."""
+def proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask=None, weight_mask=None, proto=None):
+    """-> (Wn [N,K,C], saved (hidden, gate, pool)).  proto: optional [N*way,C] output."""
     W1, b1, W2, b2, Wl, bl, weight = params
     C = S.shape[1]
     dev = S.device
     hidden, gate, pool = _f32(S.shape[0], C, device=dev), _f32(S.shape[0], C, device=dev), _f32(S.shape[0], C, device=dev)
     Wn = _f32(N, K, C, device=dev)
     call("denet_proto_extend_fwd", S, cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask,
-         N, way, shot, K, C, P, hidden, gate, pool, Wn)
+         N, way, shot, K, C, P, hidden, gate, pool, Wn, proto)
     return Wn, (hidden, gate, pool)
 
 
@@ -109,6 +109,24 @@ def classify_shared(Fq, W):
     logits = _f32(N, K, h, w, device=Fq.device)
     call("denet_classify_shared_fwd", Fq, feat_code(Fq), W.contiguous(), N, K, C, h * w, logits)
     return logits
+
+
+def binary_logits(logits, labels, way=1, base=True):
+    """get_binary_logits (utils/operations.py:313-338): logits [N,K,h,w], labels [N,way] -> [N*way,2,h,w]."""
+    logits = logits.float().contiguous()
+    N, K, h, w = logits.shape
+    labels = _as_i64(labels).contiguous()
+    out = _f32(N * way, 2, h, w, device=logits.device)
+    call("denet_binary_logits", logits, labels, N, way, K, h * w, 1 if base else 0, out)
+    return out
+
+
+def batch_mean(x):
+    """mean over dim 0 (model/common.py:371)."""
+    x = x.float().contiguous()
+    out = _f32(*x.shape[1:], device=x.device)
+    call("denet_batch_mean", x, x.shape[0], x[0].numel(), out)
+    return out
 
 
 def classify_bwd(Fq, Wn, dlog_a, dlog_b=None, scale=None, gmul=None, need_dFq=True, need_dWn=True):
@@ -265,6 +283,75 @@ class EstimatorFunction(torch.autograd.Function):
         dFs = dFs.reshape(N, way, shot, C, h, w)
         return (dFq, dFs, g["dweight"], g["dW1"], g["db1"], g["dW2"], g["db2"], g["dWl"], g["dbl"],
                 None, None, None, None, None)
+
+
+class ExtendFunction(torch.autograd.Function):
+    """WeightEstimator.extend(mode='training') alone (model/common.py:359-368):
+    (Fs, weight, W1, b1, W2, b2, Wl, bl | Ys, labels, masks) -> (Wn [N,K,C], proto [N*way,C])."""
+
+    @staticmethod
+    def forward(ctx, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, gate_mask, weight_mask):
+        N, way, shot, C, h, w = Fs.shape
+        K = weight.shape[0]
+        B, P = N * way * shot, h * w
+        mask, cnt = mask_resize(Ys.reshape(B, *Ys.shape[-2:]), h, w)
+        S = masked_sum(Fs.contiguous().reshape(B, C, h, w), mask)
+        params = tuple(t.contiguous() for t in (W1, b1, W2, b2, Wl, bl, weight))
+        labels = _as_i64(labels).contiguous()
+        proto = _f32(N * way, C, device=Fs.device)
+        Wn, saved = proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask, weight_mask, proto)
+        ctx.save_for_backward(mask, cnt, S, labels, *saved, *params,
+                              *(t for t in (gate_mask, weight_mask) if t is not None))
+        ctx.has_masks = (gate_mask is not None, weight_mask is not None)
+        ctx.dims = (N, way, shot, K, C, h, w)
+        ctx.fs_dtype = Fs.dtype
+        ctx.mark_non_differentiable(proto)
+        ctx.set_materialize_grads(False)
+        return Wn, proto
+
+    @staticmethod
+    def backward(ctx, dWn, dproto_unused):
+        N, way, shot, K, C, h, w = ctx.dims
+        if dWn is None:
+            return (None,) * 12
+        sv = ctx.saved_tensors
+        mask, cnt, S, labels, hidden, gate, pool, W1, b1, W2, b2, Wl, bl, weight = sv[:14]
+        rest = list(sv[14:])
+        gate_mask = rest.pop(0) if ctx.has_masks[0] else None
+        weight_mask = rest.pop(0) if ctx.has_masks[1] else None
+        g = proto_extend_bwd(dWn.contiguous().float(), 1, S, cnt, (hidden, gate, pool),
+                             (W1, b1, W2, b2, Wl, bl, weight), labels, N, way, shot, K, h * w, gate_mask, weight_mask)
+        dFs = masked_sum_bwd(mask, g["coef"], (N * way * shot, C, h, w), ctx.fs_dtype).reshape(N, way, shot, C, h, w)
+        return (dFs, g["dweight"], g["dW1"], g["db1"], g["dW2"], g["db2"], g["dWl"], g["dbl"], None, None, None, None)
+
+
+class ClassifyFunction(torch.autograd.Function):
+    """WeightEstimator.infer (model/common.py:390-399): (Fq [N,C,h,w], Wn [N,K,C] or W [K,C]) -> logits."""
+
+    @staticmethod
+    def forward(ctx, Fq, Wn):
+        shared = Wn.dim() == 2
+        Wn_c = Wn.float().contiguous()
+        logits = classify_shared(Fq, Wn_c) if shared else classify(Fq, Wn_c)[0]
+        ctx.save_for_backward(Fq, Wn_c)
+        ctx.shared = shared
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        Fq, Wn = ctx.saved_tensors
+        N = Fq.shape[0]
+        Wb = Wn.unsqueeze(0).expand(N, -1, -1).contiguous() if ctx.shared else Wn
+        dFq, dWn_part, n_part = classify_bwd(Fq, Wb, dlogits.contiguous().float(),
+                                             need_dFq=ctx.needs_input_grad[0], need_dWn=ctx.needs_input_grad[1])
+        dWn = None
+        if dWn_part is not None:
+            K, C = Wb.shape[1:]
+            dWn = _f32(N, K, C, device=Fq.device)
+            call("denet_sum_parts", dWn_part, N, n_part, K * C, dWn)
+            if ctx.shared:
+                dWn = dWn.sum(0)
+        return dFq, dWn
 
 
 # --------------------------------------------------------------------------

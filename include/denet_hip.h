@@ -19,7 +19,7 @@
  *      logits    [N, K, h, w] fp32
  *  - B = N*way*shot support images, P = h*w feature positions.
  *  - C (feature depth) must be 64 or 256 (the reference fixes 256: model/head/denet.py:27,47;
- *    64 exists for small test fixtures); K <= 128.
+ *    64 exists for small test fixtures); K <= 128; shot <= 8.
  */
 #ifndef DENET_HIP_H
 #define DENET_HIP_H
@@ -72,6 +72,8 @@ int denet_masked_sum_bwd(const float* mask, const float* coef /*[B,C]*/, int64_t
  * gate_mask [B,C] / weight_mask [N,K,C]: already-scaled dropout multipliers
  * (0 or 1/(1-p)) or NULL for eval mode.
  * hidden, gate, pool [B,C] are saved for the backward pass.
+ * proto [N*way,C] (may be NULL): the shot-mean prototype of every (episode, way)
+ * group, for the support_free bookkeeping (model/common.py:332-338).
  */
 int denet_proto_extend_fwd(const float* S, const float* cnt,
                            const float* W1, const float* b1, const float* W2, const float* b2,
@@ -80,7 +82,7 @@ int denet_proto_extend_fwd(const float* S, const float* cnt,
                            const float* gate_mask, const float* weight_mask,
                            int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P,
                            float* hidden, float* gate, float* pool, float* Wn /*[N,K,C]*/,
-                           void* stream);
+                           float* proto /*[N*way,C] or NULL*/, void* stream);
 
 /* Backward of K2 (autograd of the same lines).  Inputs: dWn [N,K,C] given as
  * `n_part` partial slabs [N,n_part,K,C] that are summed here (K3b writes one
@@ -116,6 +118,13 @@ int denet_classify_fwd(const void* Fq, int feat_dtype, const float* Wn, const in
 int denet_classify_shared_fwd(const void* Fq, int feat_dtype, const float* W,
                               int64_t N, int64_t K, int64_t C, int64_t P,
                               float* logits, void* stream);
+/* get_binary_logits on an existing logits tensor (utils/operations.py:313-338), same
+ * semantics as the epilogue of denet_classify_fwd.  labels [N,way] -> bin [N*way,2,P]. */
+int denet_binary_logits(const float* logits, const int64_t* labels, int64_t N, int64_t way, int64_t K,
+                        int64_t P, int base, float* logits_binary, void* stream);
+/* out[i] = mean_n x[n,i]: the batch mean of extended weights of mode='deploy'
+ * (model/common.py:369-372). */
+int denet_batch_mean(const float* x, int64_t N, int64_t per, float* out, void* stream);
 
 /* Backward of K3 (autograd of model/common.py:392-393):
  *   dL = scale[n] * (dlog_a + dlog_b)     (the two slabs K4 writes; dlog_b may be NULL,
@@ -129,6 +138,10 @@ int denet_classify_bwd(const void* Fq, int feat_dtype, const float* Wn,
                        const float* gmul /* device scalar multiplied into dL, or NULL */,
                        int64_t N, int64_t K, int64_t C, int64_t P,
                        void* dFq /* may be NULL */, float* dWn_part /* may be NULL */, void* stream);
+
+/* dWn[n,:] = sum_t dWn_part[n,t,:]: the tensor form of the classifier's weight gradient, for
+ * callers that run WeightEstimator.extend and .infer as separate autograd nodes. per_n = K*C. */
+int denet_sum_parts(const float* part, int64_t N, int64_t n_part, int64_t per_n, float* out, void* stream);
 
 /* ---- K4/K5: fused bilinear up-sampling + losses --------------------------
  * Replaces F.interpolate(bilinear, align_corners=True) of both logit tensors

@@ -245,6 +245,72 @@ def capture_fullsize_checksums():
     print("c2_fullsize.npz loss_k=%.6f loss_p=%.6f" % (float(lk), float(lp)))
 
 
+def capture_api_cases():
+    """Secondary API surface (SURVEY.md §8a K2', §8f N1) and the loss functions called the way a
+    user of the reference calls them: deploy mode, support_free, get_binary_logits(base=False),
+    cross_entropy2d / binary_focal_loss on a batch (low-res and same-size), state_dict keys."""
+    import json
+    s = EpisodeShape("api", N=3, way=2, shot=3, K=9, c=64, h=7, w=9, H=50, W=70, config_index=104)
+    ep = make_episodes(s, ignore_rows=3)
+    # make labels overlap across episodes and inside one episode (support_free keeps the FIRST)
+    ep["label"] = torch.tensor([[3, 5], [5, 2], [4, 4]])
+    state = make_estimator_state(s.K, s.c)
+    d = {("in:" + k): v.float().numpy() if v.is_floating_point() else v.numpy() for k, v in ep.items()}
+    d.update({("param:" + k): v.numpy() for k, v in state.items()})
+    d["shape"] = np.array([s.N, s.way, s.shot, s.K, s.c, s.h, s.w, s.H, s.W], dtype=np.int64)
+    Fq, Fs = ep["Fq"].float(), ep["Fs"].float()
+    with torch.no_grad():
+        # ---- deploy: extend + infer, then infer only (model/common.py:427-441)
+        we = build_estimator(s.K, s.c, state).eval()
+        d["out:deploy_logits"] = we(Fq, Fs, ep["Ys"], ep["label"], mode="deploy").numpy()
+        d["out:deploy_weight"] = we.weight.data.clone().numpy()
+        d["out:deploy_infer_only"] = we(Fq.flip(0), mode="deploy").numpy()
+        # ---- support_free (model/common.py:326-338), two consecutive batches
+        wf = ref_common.WeightEstimator(num_classes=s.K, depth=s.c, support_free=True)
+        wf.load_state_dict(state)
+        wf.eval()
+        d["out:sfree_weights1"] = wf.extend(Fs, ep["Ys"], ep["label"]).numpy()
+        d["out:sfree_persist1"] = wf.weight.data.clone().numpy()
+        lab2 = torch.tensor([[1, 3], [6, 7], [2, 8]])
+        d["in:label2"] = lab2.numpy()
+        d["out:sfree_logits2"] = wf(Fq, Fs.flip(0), ep["Ys"].flip(0), lab2, mode="training").numpy()
+        d["out:sfree_persist2"] = wf.weight.data.clone().numpy()
+        d["out:sfree_record"] = np.array([int(wf.record[k]) for k in range(s.K)], dtype=np.int64)
+        # ---- get_binary_logits(base=False) (utils/operations.py:334-336)
+        we2 = build_estimator(s.K, s.c, state).eval()
+        full = we2(Fq, Fs, ep["Ys"], ep["label"], mode="training")
+        d["out:full"] = full.numpy()
+        d["out:bin_base_false"] = ref_ops.get_binary_logits(full, ep["label"][:, 1], base=False).numpy()
+        d["out:bin_base_true"] = ref_ops.get_binary_logits(full, ep["label"][:, 1], base=True).numpy()
+    # ---- losses on a batch, with gradients w.r.t. the logits
+    g = torch.Generator().manual_seed(77)
+    cw = torch.rand(s.K, generator=g) + 0.5
+    d["in:class_weight"] = cw.numpy()
+    for tag, x in (("low", full.clone()), ("same", torch.randn(s.N, s.K, s.H, s.W, generator=g))):
+        x = x.requires_grad_(True)
+        l = ref_losses.cross_entropy2d(x, ep["Yq_full"], weight=cw)
+        l.backward()
+        d[f"in:ce_{tag}"] = x.detach().numpy()
+        d[f"out:ce_{tag}"] = l.detach().numpy()
+        d[f"out:ce_{tag}_grad"] = x.grad.numpy()
+    d["out:loss_general"] = ref_losses.loss_general(full, ep["Yq_full"]).numpy()
+    xb = torch.randn(s.N, 2, s.H, s.W, generator=g)
+    d["in:focal_same"] = xb.numpy()
+    d["out:focal_same"] = ref_losses.binary_focal_loss(xb, ep["Yq"][:, 0].contiguous()).numpy()
+    d["out:focal_low"] = ref_losses.loss_denet(torch.from_numpy(d["out:bin_base_true"]), ep["Yq"][:, 1].contiguous(), mode="pattern").numpy()
+    # ---- state_dict layout a reference checkpoint carries (SURVEY.md §8b)
+    emb = torch.nn.Sequential(torch.nn.Conv2d(1024, 256, kernel_size=3, padding=2, dilation=2), torch.nn.ReLU(),
+                              torch.nn.Dropout2d(p=0.5))
+    keys = {}
+    for prefix, mod in (("embedding.", emb), ("deeplab_head.", ref_common.DeepLabHead(256)),
+                        ("estimator.", ref_common.WeightEstimator(21, 256))):
+        for k, v in mod.state_dict().items():
+            keys[prefix + k] = list(v.shape)
+    d["state_dict_layout"] = np.array(json.dumps(keys))
+    np.savez_compressed(os.path.join(OUT, "api_cases.npz"), **d)
+    print("api_cases.npz", len(keys), "state_dict entries")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -259,3 +325,4 @@ if __name__ == "__main__":
     capture_metrics()
     capture_index_tables()
     capture_fullsize_checksums()
+    capture_api_cases()

@@ -24,6 +24,6 @@ def load_case(name):
 
 
 def rel_err(a, b):
-    a = torch.as_tensor(a).double()
-    b = torch.as_tensor(b).double()
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

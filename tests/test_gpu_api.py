@@ -1,0 +1,219 @@
+"""GPU: the host-side mirror of the reference interface (denet_amd.head / losses /
+metrics / trainer) driven the way a user of the reference drives it, against the
+golden fixtures captured from the reference's own classes."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, GOLDEN, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-5
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _estimator(params, K, c, dev, **kw):
+    from denet_amd.head import WeightEstimator
+    we = WeightEstimator(K, c, **kw)
+    we.load_state_dict(params)
+    return we.to(dev)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if not c.startswith("train")])
+def test_weight_estimator_module_eval(name, dev):
+    z, d, ep, params, gm, wm = load_case(name)
+    we = _estimator(params, d["K"], d["c"], dev).eval()
+    N, way = d["N"], d["way"]
+    lab = ep["label"].reshape(N, way).to(dev)
+    Fq, Fs, Ys = ep["Fq"].float().to(dev), ep["Fs"].float().to(dev), ep["Ys"].to(dev)
+    # forward() = extend + infer (model/common.py:421-426)
+    logits = we(Fq, Fs, Ys, lab, mode="training")
+    assert rel_err(logits.cpu(), z["out:logits_full"]) < TIGHT
+    # the two halves on their own, and differentiable through both
+    Fq.requires_grad_(True)
+    Fs.requires_grad_(True)
+    Wn = we.extend(Fs, Ys, lab)
+    if "out:weights" in z.files:
+        assert rel_err(Wn.detach().cpu(), z["out:weights"]) < TIGHT
+    logits2 = we.infer(Fq, Wn)
+    assert torch.equal(logits2.detach(), logits.detach())
+    from denet_amd.losses import loss_denet_batch
+    full, binl = we.forward_with_binary(Fq, Fs, Ys, lab)
+    assert rel_err(binl.cpu(), z["out:logits_binary"]) < TIGHT
+    lk, lp = loss_denet_batch(logits2, ep["Yq_full"].to(dev), binl, ep["Yq"].to(dev), ep["wgt"].to(dev))
+    lk.backward()
+    assert rel_err(lk.detach().cpu(), z["out:loss_k"]) < 1e-4
+    assert rel_err(lp.cpu(), z["out:loss_p"]) < 1e-4
+    assert rel_err(Fq.grad.cpu(), z["out:dFq"]) < TOL
+    assert rel_err(Fs.grad.cpu(), z["out:dFs"]) < TOL
+    for k, p in we.named_parameters():
+        assert rel_err(p.grad.cpu(), z["grad:" + k]) < TOL, k
+
+
+def test_weight_estimator_train_mode_with_injected_masks(dev):
+    z, d, ep, params, gm, wm = load_case("train_1way_5shot")
+    we = _estimator(params, d["K"], d["c"], dev).train()
+    lab = ep["label"].reshape(d["N"], d["way"]).to(dev)
+    full, binl = we.forward_with_binary(ep["Fq"].float().to(dev), ep["Fs"].float().to(dev), ep["Ys"].to(dev), lab,
+                                        gate_mask=gm.to(dev), weight_mask=wm.to(dev).contiguous())
+    assert rel_err(full.cpu(), z["out:logits_full"]) < TIGHT
+    # self-drawn masks: keep-probability 0.5, scale 2 (nn.Dropout(0.5)); statistics only
+    g, w_ = we._dropout_masks(64, 4, dev)
+    assert set(g.unique().tolist()) <= {0.0, 2.0} and set(w_.unique().tolist()) <= {0.0, 2.0}
+    assert 0.4 < float((g > 0).float().mean()) < 0.6 and w_.shape == (4, d["K"], d["c"])
+    we.eval()
+    assert we._dropout_masks(64, 4, dev) == (None, None)
+
+
+def test_deploy_support_free_and_base_false(dev):
+    """SURVEY.md §8a K2' / §8f N1 against the reference's own run (tests/golden/api_cases.npz)."""
+    from denet_amd.head import WeightEstimator
+    from denet_amd.operations import get_binary_logits
+    z = np.load(GOLDEN + "/api_cases.npz")
+    N, way, shot, K, c, h, w, H, W = [int(v) for v in z["shape"]]
+    params = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
+    Fq, Fs = torch.from_numpy(z["in:Fq"]).to(dev), torch.from_numpy(z["in:Fs"]).to(dev)
+    Ys, lab = torch.from_numpy(z["in:Ys"]).to(dev), torch.from_numpy(z["in:label"]).to(dev)
+    # deploy: persist the batch mean of the extended weights, classify with it
+    we = _estimator(params, K, c, dev).eval()
+    out = we(Fq, Fs, Ys, lab, mode="deploy")
+    assert rel_err(out.cpu(), z["out:deploy_logits"]) < TIGHT
+    assert rel_err(we.weight.data.cpu(), z["out:deploy_weight"]) < TIGHT
+    assert rel_err(we(Fq.flip(0).contiguous(), mode="deploy").cpu(), z["out:deploy_infer_only"]) < TIGHT
+    # support_free: first insertion wins and persists, across two batches
+    wf = WeightEstimator(K, c, support_free=True)
+    wf.load_state_dict(params)
+    wf = wf.to(dev).eval()
+    w1 = wf.extend(Fs, Ys, lab)
+    assert rel_err(w1.cpu(), z["out:sfree_weights1"]) < TIGHT
+    assert rel_err(wf.weight.data.cpu(), z["out:sfree_persist1"]) < TIGHT
+    lab2 = torch.from_numpy(z["in:label2"]).to(dev)
+    l2 = wf(Fq, Fs.flip(0).contiguous(), Ys.flip(0).contiguous(), lab2, mode="training")
+    assert rel_err(l2.cpu(), z["out:sfree_logits2"]) < TIGHT
+    assert rel_err(wf.weight.data.cpu(), z["out:sfree_persist2"]) < TIGHT
+    assert [int(wf.record[k]) for k in range(K)] == list(z["out:sfree_record"])
+    # get_binary_logits, both variants
+    full = torch.from_numpy(z["out:full"]).to(dev)
+    assert torch.equal(get_binary_logits(full, lab[:, 1], base=False).cpu(), torch.from_numpy(z["out:bin_base_false"]))
+    assert torch.equal(get_binary_logits(full, lab[:, 1], base=True).cpu(), torch.from_numpy(z["out:bin_base_true"]))
+
+
+def test_loss_functions_called_like_the_reference(dev):
+    from denet_amd import losses
+    z = np.load(GOLDEN + "/api_cases.npz")
+    yf = torch.from_numpy(z["in:Yq_full"]).to(dev)
+    cw = torch.from_numpy(z["in:class_weight"]).to(dev)
+    for tag in ("low", "same"):
+        x = torch.from_numpy(z[f"in:ce_{tag}"]).to(dev).requires_grad_(True)
+        loss = losses.cross_entropy2d(x, yf, weight=cw)
+        loss.backward()
+        assert rel_err(loss.detach().cpu(), z[f"out:ce_{tag}"]) < 1e-4, tag
+        assert rel_err(x.grad.cpu(), z[f"out:ce_{tag}_grad"]) < TOL, tag
+    full = torch.from_numpy(z["out:full"]).to(dev)
+    assert rel_err(losses.loss_general(full, yf).cpu(), z["out:loss_general"]) < 1e-4
+    yq = torch.from_numpy(z["in:Yq"]).to(dev)
+    xb = torch.from_numpy(z["in:focal_same"]).to(dev)
+    assert rel_err(losses.binary_focal_loss(xb, yq[:, 0].contiguous()).cpu(), z["out:focal_same"]) < 1e-4
+    low = torch.from_numpy(z["out:bin_base_true"]).to(dev)
+    assert rel_err(losses.loss_denet(low, yq[:, 1].contiguous(), mode="pattern").cpu(), z["out:focal_low"]) < 1e-4
+    f = losses.get_loss({"name": "loss_denet"})
+    assert rel_err(f(full, yf, mode="knowledge").cpu(), z["out:loss_general"]) < 1e-4
+
+
+def test_metric_classes_on_device(dev):
+    """FullIOU / BinaryIOU fed like the reference's trainer feeds them (up-sampled logits)."""
+    from denet_amd.metrics import BinaryIOU, FullIOU
+    z = np.load(GOLDEN + "/metrics.npz")
+    K = z["out:mat"].shape[0]
+    fi, bi = FullIOU(num_classes=K), BinaryIOU()
+    for u in range(3):
+        fi.update(torch.from_numpy(z[f"in:yt{u}"]).to(dev), torch.from_numpy(z[f"in:lp{u}"]).to(dev))
+        bi.update(torch.from_numpy(z[f"in:yb{u}"]).to(dev), torch.from_numpy(z[f"in:lb{u}"]).to(dev), z[f"in:cls{u}"])
+    assert np.array_equal(fi.mat, z["out:mat"].astype(np.float64))
+    assert fi.mean_iou() == float(z["out:miou"])
+    assert list(bi.inter.keys()) == list(z["out:biou_keys"])
+    assert bi.mean_iou() == float(z["out:biou_mean"]) and bi.mean_bf_iou() == float(z["out:biou_bf"])
+
+
+def test_denet_module_with_stub_backbone(dev):
+    """DENet.forward end to end (model/head/denet.py:52-93): stock PyTorch-ROCm producer, HIP head,
+    against the same modules' producer on the CPU feeding the oracle's head."""
+    from denet_amd.head import DENet
+    from denet_amd.trainer import SyntheticBackbone, SyntheticEpisodes
+    from oracle import denet_oracle as O
+    torch.manual_seed(0)
+    m = DENet(backbone=SyntheticBackbone(), maximum_num_classes=21).eval()
+    Is, Ys, Iq, Yq, cls, Ys_full, Yq_full = SyntheticEpisodes(1, 2, 1, 2, 21, 65, split='val').batch(0)
+    with torch.no_grad():
+        N, way, shot = Is.shape[:3]
+        Fs = m.features(Is.reshape(-1, *Is.shape[3:])).reshape(N, way, shot, 256, 9, 9)
+        Fq = m.features(Iq)
+        state = {k: v.detach().clone() for k, v in m.estimator.state_dict().items()}
+        ref_full, ref_bin, _ = O.head_forward(Fq, Fs, Ys, cls, state)
+    m = m.to(dev)
+    with torch.no_grad():
+        full, binl = m(Is.to(dev), Ys.to(dev), Iq.to(dev), cls.to(dev))
+    assert full.shape == (2, 21, 9, 9) and binl.shape == (2, 2, 9, 9)
+    assert rel_err(full.cpu(), ref_full) < TOL          # MIOpen vs oneDNN convolutions upstream
+    assert rel_err(binl.cpu(), ref_bin) < TOL
+    assert set(m.vis) == {"hidden_Fs", "hidden_Fq"}
+
+
+def test_trainer_train_val_test_roundtrip(dev, tmp_path):
+    """DENetTrainer: a few optimisation steps lower the loss on a fixed synthetic stream, the
+    checkpoint has the reference's keys, and test() runs the 2-way path with per-way BinaryIOU."""
+    from denet_amd.trainer import DENetTrainer, get_trainer
+    cfg = {
+        "model": {"arch": "DENet", "backbone": "synthetic", "maximum_num_classes": 21},
+        "data": {"train_dataset": "synthetic", "val_dataset": "synthetic", "img_size": 65, "shot": 2,
+                 "batch_size": 4, "batches_per_epoch": 3, "val_batches": 1},
+        "train": {"trainer": "DENetTrainer", "device": 0, "num_steps": 6, "log_steps": 100, "val_steps": 6,
+                  "lambda": 2.0, "logdir": str(tmp_path),
+                  "optimizer": {"name": "sgd", "lr": 0.05, "momentum": 0.9}, "loss": {"name": "loss_denet"}},
+    }
+    assert get_trainer("DENetTrainer") is DENetTrainer
+    torch.manual_seed(0)
+    tr = DENetTrainer(cfg)
+    batch = tr.train_loader.batch(0)
+    with torch.no_grad():
+        first = tr.step(batch, train=False)                # eval mode: deterministic loss
+    assert len(first) == 5 and first[0].shape == (4, 2, 9, 9) and first[1].shape == (4, 21, 9, 9)
+    assert abs(first[2] - (first[3] + first[4])) < 1e-5
+    before = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+    out = tr.step(batch, train=True)
+    assert all(np.isfinite(v) for v in out[2:])
+    # one optimiser step moved every trainable tensor (head through the HIP backward, conv stack
+    # through dFq/dFs), and left the frozen backbone alone; labels are random, so the loss itself
+    # sits at log(K) and is not expected to fall
+    after = tr.model.state_dict()
+    for k, v in before.items():
+        moved = not torch.equal(after[k], v)
+        if k.startswith("backbone."):
+            assert not moved, k
+        elif k.endswith("weight") or k.endswith("bias"):
+            assert moved, k
+    assert float(tr.bucket.flat.abs().sum()) > 0
+    tr.train()
+    ck = torch.load(str(tmp_path / "latest_model.bin"), weights_only=True)
+    assert set(ck) == {"best_step", "epoch", "best_bIOU", "model", "optimizer", "scheduler"}
+    assert "estimator.gam.gate.0.weight" in ck["model"]
+    tcfg = {
+        "model": {"arch": "DENet", "backbone": "synthetic", "maximum_num_classes": 21},
+        "data": {"dataset": "synthetic", "img_size": 65, "fold": 0, "way": 2, "shot": 2, "batch_size": 4,
+                 "num_batches": 2},
+        "test": {"trainer": "DENetTrainer", "device": 0, "id": "t", "best": True,
+                 "ckpt_file": str(tmp_path / "latest_model.bin")},
+    }
+    te = DENetTrainer(train_config=None, test_config=tcfg)
+    out = te.step(te.test_loader.batch(0), train=False)
+    assert len(out) == 2 and out[0].shape == (8, 2, 9, 9)
+    mb, mf = te.test()
+    assert 0.0 <= mb <= 1.0 and 0.0 <= mf <= 1.0
+    with pytest.raises(ValueError):
+        DENetTrainer(cfg, tcfg)
