@@ -87,7 +87,7 @@ __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(
     const int c0 = xsid * cw, c1 = min(w, c0 + cw);
     const int cell_lo = (GRAD && c0 > 0) ? c0 - 1 : c0;
     const int ncell = c1 - cell_lo;                       // cells processed
-    const int ncmax = cw + 1;                             // LDS stride bound for cells / columns
+    const int ncmax = cw + (GRAD ? 2 : 1);                // LDS stride: cells + right tap (+ left halo cell)
     const int col_hi = min(c1, w - 1);                    // last logits column needed
     const int ncol = col_hi - cell_lo + 1;
 
@@ -439,7 +439,7 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
     for (int cw = want < w ? want : w; cw >= 1; --cw) {
         const int xsplit = (w + cw - 1) / cw;
         const int cwe = (w + xsplit - 1) / xsplit;          // the width the kernel derives from xsplit
-        const int ncmax = cwe + 1;
+        const int ncmax = cwe + (grad ? 2 : 1);           // must match the kernel's stride
         int xw_max = 0;
         for (int xsid = 0; xsid < xsplit; ++xsid) {
             const int c0 = xsid * cwe, c1 = c0 + cwe < w ? c0 + cwe : w;

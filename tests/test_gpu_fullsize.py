@@ -1,0 +1,185 @@
+"""GPU: parity at BASELINE.json's full sizes.
+
+  * C2 (1-way 5-shot, K=21, 256x41x41, 321x321): the fused head step against the checksums and
+    sampled entries captured from the reference itself (tests/golden/c2_fullsize.npz).
+  * C3 (2-way 5-shot, K=81, N=20) and C5 (2x spatial, bf16 features): against the oracle run here
+    on the same seeded episodes (seconds on the host), plus size-independent properties:
+    linearity of the classifier, conservation of pixel counts in the confusion matrix, zero
+    gradient outside the support masks, idempotence of the metric accumulation.
+  * edge cases the reference's semantics define: empty support mask, an episode whose labels are
+    all ignored (loss = 0/0 = NaN there too), one-episode batches, non-square feature maps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+ORDER = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+         "map.linear.weight", "map.linear.bias"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _run_step(shape, dev, ep=None, backward=True):
+    from denet_amd import ops
+    from denet_amd.synthetic import make_episodes, make_estimator_state
+    ep = ep or make_episodes(shape)
+    state = make_estimator_state(shape.K, shape.c)
+    P = [state[k].to(dev).requires_grad_(backward) for k in ORDER]
+    Fq = ep["Fq"].to(dev).requires_grad_(backward)
+    Fs = ep["Fs"].to(dev).requires_grad_(backward)
+    lab = ep["label"].reshape(shape.N, shape.way).to(dev)
+    lk, lp, logits, binl = ops.HeadStepFunction.apply(
+        Fq, Fs, *P, ep["Ys"].to(dev), lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+    if backward:
+        lk.backward()
+    torch.cuda.synchronize()
+    return ep, state, dict(loss_k=lk.detach(), loss_p=lp, logits_full=logits, logits_binary=binl, Fq=Fq, Fs=Fs, P=P)
+
+
+def test_c2_fullsize_against_reference_checksums(dev):
+    from denet_amd.synthetic import CONFIGS
+    z = np.load(GOLDEN + "/c2_fullsize.npz")
+    ep, state, out = _run_step(CONFIGS["C2"], dev)
+    assert rel_err(out["loss_k"].cpu(), z["out:loss_k"]) < 2e-5
+    assert rel_err(out["loss_p"].cpu(), z["out:loss_p"]) < 2e-5
+    got = {"logits_full": out["logits_full"], "logits_binary": out["logits_binary"], "dFq": out["Fq"].grad,
+           "dFs": out["Fs"].grad}
+    got.update({"grad:" + k: t.grad for k, t in zip(ORDER, out["P"])})
+    for name, t in got.items():
+        flat = t.detach().reshape(-1).cpu()
+        ref = torch.from_numpy(z["val:" + name])
+        assert rel_err(flat[torch.from_numpy(z["idx:" + name])], ref) < 1e-3, name
+        scale = float(z["abs:" + name])
+        assert abs(float(flat.double().sum()) - float(z["sum:" + name])) < 1e-4 * scale + 1e-12, name
+        assert abs(float(flat.double().abs().sum()) - scale) < 1e-4 * scale + 1e-12, name
+
+
+def _confmat_check(logits, ep, K, dev, margin=1e-4):
+    """Fused confusion matrix vs the oracle's up-sample + arg-max: pixels whose top-2 margin is
+    above `margin` must be counted identically; the rest may flip and are reported."""
+    from denet_amd import ops
+    from oracle import denet_oracle as O
+    H, W = ep["Yq_full"].shape[-2:]
+    up = O.upsample(logits.detach().cpu().float(), (H, W))
+    top = up.topk(2, dim=1)[0]
+    safe = (top[:, 0] - top[:, 1]) > margin
+    yt = ep["Yq_full"].clone()
+    sub = int((~safe & (yt != 255)).sum())
+    yt[~safe] = 255                                       # take the sub-margin pixels out of both sides
+    mat = torch.zeros(K, K, dtype=torch.int64, device=dev)
+    ops.confmat_update(mat, yt.to(dev), logits)
+    ref = O.confusion_matrix(yt.numpy(), up.argmax(1).numpy(), K)
+    assert np.array_equal(mat.cpu().numpy(), ref)
+    assert int(mat.sum()) == int(((yt >= 0) & (yt < K)).sum())            # every valid pixel counted once
+    ops.confmat_update(mat, yt.to(dev), logits)                            # accumulation: twice = 2x
+    assert np.array_equal(mat.cpu().numpy(), 2 * ref)
+    return sub
+
+
+def test_c3_forward_and_metrics_against_oracle(dev):
+    from denet_amd import ops
+    from denet_amd.synthetic import CONFIGS
+    from oracle import denet_oracle as O
+    s = CONFIGS["C3"]
+    ep, state, out = _run_step(s, dev, backward=False)
+    with torch.no_grad():
+        ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state,
+                          backward=False)
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["logits_binary"].cpu(), ref["logits_binary"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(out["loss_p"].cpu(), ref["loss_p"]) < 1e-4
+    sub = _confmat_check(out["logits_full"], ep, s.K, dev)
+    print(f"C3: {sub} sub-margin pixels excluded of {ep['Yq_full'].numel()}")
+    # BinaryIOU counts per way, skip rule included
+    H, W = s.H, s.W
+    bup = O.upsample(ref["logits_binary"], (H, W))
+    safe = (bup[:, 1] - bup[:, 0]).abs() > 1e-4
+    yq = ep["Yq"].reshape(-1, H, W)
+    cnt = ops.binary_counts(yq.to(dev), out["logits_binary"]).cpu().numpy()
+    pred = bup.max(1)[1].numpy()
+    for i, (t, q, ok) in enumerate(zip(yq.numpy(), pred, safe.numpy())):
+        assert cnt[i, 0] == t.sum()
+        slack = int((~ok).sum())
+        assert abs(int(cnt[i, 1]) - int(((t + q) == 2).sum())) <= slack
+        assert abs(int(cnt[i, 2]) - int((((t + q) == 1) | ((t + q) == 2)).sum())) <= slack
+    assert (cnt[:, 0] == 0).any()                         # the planted all-zero query mask is present
+
+
+def test_c5_bf16_large_resolution_against_oracle(dev):
+    from denet_amd.synthetic import CONFIGS, EpisodeShape
+    from oracle import denet_oracle as O
+    s = EpisodeShape(**{**CONFIGS["C5"].asdict(), "N": 2})           # full resolution, 2 episodes: host oracle in seconds
+    ep, state, out = _run_step(s, dev)
+    assert out["Fq"].dtype == torch.bfloat16 and out["Fs"].grad.dtype == torch.bfloat16
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    # bf16 inputs are exact in fp32; accumulation is fp32 on both sides
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(out["loss_p"].cpu(), ref["loss_p"]) < 1e-4
+    # feature gradients are rounded to bf16 on the way out (8 significant bits)
+    assert rel_err(out["Fq"].grad.float().cpu(), ref["dFq"]) < 8e-3
+    assert rel_err(out["Fs"].grad.float().cpu(), ref["dFs"]) < 8e-3
+    for k, t in zip(ORDER, out["P"]):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
+    _confmat_check(out["logits_full"], ep, s.K, dev)
+
+
+def test_properties_at_full_size(dev):
+    """Size-independent properties on C2: classifier linearity, masked-gradient support."""
+    from denet_amd import ops
+    from denet_amd.synthetic import CONFIGS, make_episodes
+    s = CONFIGS["C2"]
+    ep = make_episodes(s)
+    Fq = ep["Fq"].to(dev)
+    Wn = torch.randn(s.N, s.K, s.c, device=dev)
+    a, _ = ops.classify(Fq, Wn)
+    b, _ = ops.classify(2.0 * Fq, Wn)
+    assert torch.equal(b, 2.0 * a)                        # scaling by a power of two is exact
+    c, _ = ops.classify(Fq, Wn.flip(1).contiguous())
+    assert torch.equal(c, a.flip(1))                      # class rows are independent
+    _, _, out = _run_step(s, dev, ep=ep)
+    B, P = s.N * s.way * s.shot, s.h * s.w
+    mask, cnt = ops.mask_resize(ep["Ys"].reshape(B, s.H, s.W).to(dev), s.h, s.w)
+    dFs = out["Fs"].grad.reshape(B, s.c, P)
+    assert float((dFs * (1 - mask).unsqueeze(1)).abs().max()) == 0.0      # no gradient outside the mask
+    assert float(cnt[0]) == 0.0 and torch.isfinite(out["logits_full"]).all()   # empty mask: den + 1e-3
+
+
+def test_edge_cases(dev):
+    from denet_amd import ops
+    from denet_amd.synthetic import EpisodeShape, make_episodes
+    from oracle import denet_oracle as O
+    # one episode, non-square maps, position count not a multiple of the 64-wide tile
+    s = EpisodeShape("edge", N=1, way=1, shot=1, K=3, c=64, h=5, w=13, H=33, W=97, config_index=9, lam=0.5)
+    ep = make_episodes(s, ignore_rows=2)
+    ep["Ys"][0, 0, 0, ::2] = 1                            # make_episodes empties the first support mask
+    _, state, out = _run_step(s, dev, ep=ep)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert float(ref["dFs"].abs().max()) > 0 and rel_err(out["Fs"].grad.cpu(), ref["dFs"]) < 1e-3
+    assert rel_err(out["Fq"].grad.cpu(), ref["dFq"]) < 1e-3
+    # an episode whose labels are all ignored: weighted mean over nothing = NaN, as in the reference
+    s2 = EpisodeShape("edge2", N=2, way=1, shot=2, K=5, c=64, h=9, w=9, H=65, W=65, config_index=10)
+    ep2 = make_episodes(s2, ignore_rows=2)
+    ep2["Yq_full"][1] = 255
+    _, state2, out2 = _run_step(s2, dev, ep=ep2, backward=False)
+    ref2 = O.head_step(ep2["Fq"], ep2["Fs"], ep2["Ys"], ep2["label"], ep2["Yq"], ep2["Yq_full"], ep2["wgt"], state2,
+                       backward=False)
+    assert torch.isnan(ref2["loss_k"]) and torch.isnan(out2["loss_k"].cpu())
+    assert rel_err(out2["loss_p"].cpu(), ref2["loss_p"]) < 1e-4
+    # confusion matrix ignores every out-of-range label, not only 255
+    yt = torch.tensor([[[0, 1, 2, 7, -1, 255, 254, 3]]])
+    pr = torch.zeros(1, 3, 1, 8)
+    pr[0, 2] = 1.0
+    mat = torch.zeros(3, 3, dtype=torch.int64, device=dev)
+    ops.confmat_update(mat, yt.to(dev), pr.to(dev))
+    assert mat.cpu().tolist() == [[0, 0, 1], [0, 0, 1], [0, 0, 1]]
