@@ -53,7 +53,9 @@ def kernel_bytes(s: EpisodeShape, sF: int):
         "focal_fwd": NB * Q * 8 + NB * 2 * P * 4,
         "loss_finalize": (N + NB) * s.h * 8,
         "classify_bwd": 2 * N * C * P * sF + 2 * N * K * P * 4 + N * K * C * 4 + N * n_part * K * C * 4,
-        "proto_extend_bwd": N * n_part * K * C * 4 * 2 + 3 * C * C * 4 * 2 + 8 * B * C * 4,
+        "pe_bwd_reduce": N * n_part * K * C * 4 + N * K * C * 4,
+        "pe_bwd_chain": 3 * C * C * 4 + N * way * C * 4 + 7 * B * C * 4,
+        "pe_bwd_params": 6 * B * C * 4 + N * K * C * 4 + 3 * C * C * 4 + K * C * 4,
         "masked_sum_bwd": B * C * P * sF + B * P * 4 + B * C * 4,
     }
 
@@ -67,6 +69,22 @@ def step_bytes_per_episode(s: EpisodeShape, sF: int) -> float:
     return float(fwd + bwd)
 
 
+def pmc_traffic(kernel: str, config: str, episodes: int):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
+    written by scripts/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    runs of this same command; reads doubled per MI355X_MICROARCH.md §HBM).  None if the passes were
+    taken at another batch size or are absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("config") != config or d.get("episodes") != episodes:
+        return None
+    return d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +94,11 @@ def main():
     ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default: the config's batch)")
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured HIP graph")
     ap.add_argument("--probe", default="auto", help="kernel to time with HIP events (name | auto | none)")
+    ap.add_argument("--probe-every", type=int, default=8,
+                    help="bracket the probed kernel with HIP events on every n-th timed step (an event pair "
+                         "costs a few microseconds of stream time, so not on every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (seconds)")
     ap.add_argument("--breakdown", type=int, default=1, help="also report every kernel's duration (untimed pass)")
     args = ap.parse_args()
 
@@ -153,16 +175,20 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region ----
-    pairs = []
+    pairs = {}
     if probe and graph is None:
-        pairs = [(Event(), Event()) for _ in range(args.steps)]
+        every = max(1, args.probe_every)
+        pairs = {i: (Event(), Event()) for i in range(0, args.steps, every)}
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if pairs:
-            eng.set_probe(probe, *pairs[i])
+            if i in pairs:
+                eng.set_probe(probe, *pairs[i])
+            elif (i - 1) in pairs:
+                eng.set_probe(None, None, None)
         runner()
     torch.cuda.synchronize()
     if dist is not None:
@@ -177,7 +203,7 @@ def main():
 
     probe_us = None
     if pairs:
-        probe_us = statistics.mean(a.elapsed_ms(b) * 1e3 for a, b in pairs)
+        probe_us = statistics.mean(a.elapsed_ms(b) * 1e3 for a, b in pairs.values())
     elif probe:
         probe_us = breakdown.get(probe)
 
@@ -190,8 +216,9 @@ def main():
     if probe and probe_us:
         ach = kb[probe] / (probe_us * 1e-6) / 1e9
         roofline = {"kernel": probe, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": kb[probe], "us_per_launch": round(probe_us, 2)}
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(probe, args.config, N),
+                    "bytes_per_launch": kb[probe], "us_per_launch": round(probe_us, 2),
+                    "probed_steps": len(pairs) if pairs else 0}
     spb = step_bytes_per_episode(shape, sF)
     step_roof = {"bytes_per_episode": spb, "achieved": round(value / world * spb / 1e9, 1), "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": round(value / world * spb / 1e9 / HBM_PEAK_GBS, 4)}
@@ -202,15 +229,17 @@ def main():
         nthreads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
         torch.set_num_threads(nthreads)
         ts = []
-        for i in range(4):
+        budget = time.perf_counter() + args.cpu_seconds
+        while len(ts) < 4 or (time.perf_counter() < budget and len(ts) < 400):
             c0 = time.perf_counter()
             O.head_step(ep_cpu["Fq"], ep_cpu["Fs"], ep_cpu["Ys"], ep_cpu["label"], ep_cpu["Yq"], ep_cpu["Yq_full"],
                         ep_cpu["wgt"], state_cpu)
             ts.append(time.perf_counter() - c0)
         med = statistics.median(ts[1:])
         cpu = {"value": round(N / med, 3), "unit": "episodes/s", "cores": nthreads, "kind": "port",
-               "sample": f"1 warm-up + 3 timed steps of the same {args.config} batch ({N} episodes), "
-                         f"oracle head_step (fwd + both losses + loss_k.backward), median {med * 1e3:.0f} ms/step"}
+               "sample": f"1 warm-up + {len(ts) - 1} timed steps (~{sum(ts):.0f} s) of the same {args.config} batch "
+                         f"({N} episodes), oracle head_step (fwd + both losses + loss_k.backward), "
+                         f"median {med * 1e3:.0f} ms/step"}
 
     if rank == 0:
         out = {

@@ -60,7 +60,8 @@ class Probe(ctypes.Structure):
 
 
 KERNEL_IDS = {"mask_resize": 1, "masked_sum_fwd": 2, "proto_extend_fwd": 3, "classify_fwd": 4, "wce_fwd": 5,
-              "focal_fwd": 6, "loss_finalize": 7, "classify_bwd": 8, "proto_extend_bwd": 9, "masked_sum_bwd": 10}
+              "focal_fwd": 6, "loss_finalize": 7, "classify_bwd": 8, "pe_bwd_reduce": 11, "pe_bwd_chain": 9,
+              "pe_bwd_params": 12, "masked_sum_bwd": 10}
 
 EXPORTS = sorted(list(_SIGS) + list(_NOSTREAM))
 

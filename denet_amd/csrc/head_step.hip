@@ -126,10 +126,21 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     PROBED(DENET_K_CLASSIFY_BWD,
            denet_classify_bwd(Fq, feat_dtype, s.Wn, s.dlog_a, s.dlog_b, s.scale, grad_loss_k, N, K, C, P, dFq,
                               s.dWn_part, stream));
-    PROBED(DENET_K_PROTO_EXTEND_BWD,
-           denet_proto_extend_bwd(s.dWn_part, n_part, s.S, s.cnt, s.hidden, s.gate, s.pool, W1, W2, Wl, labels,
-                                  gate_mask, weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl,
-                                  dweight, s.coef, s.u, (3 * B * C + N * K * C) * 4, stream));
+    if (!dW1 || !db1 || !dW2 || !db2 || !dWl || !dbl || !dweight || !labels || !W1 || !W2 || !Wl)
+        return DENET_E_BADARG;
+    if (!(C == 64 || C == 256) || K > 128 || shot > 8 || N > 65535) return DENET_E_UNSUPPORTED;
+    float *u1 = s.u, *u2 = u1 + B * C, *u3 = u2 + B * C, *dWn = u3 + B * C;
+    const float* dWn_src = s.dWn_part;
+    if (n_part > 1) {
+        PROBED(DENET_K_PE_BWD_REDUCE, denet_pe_bwd_reduce(s.dWn_part, n_part, N, K, C, dWn, stream));
+        dWn_src = dWn;
+    }
+    PROBED(DENET_K_PE_BWD_CHAIN,
+           denet_pe_bwd_chain(dWn_src, s.S, s.cnt, s.hidden, s.gate, W1, W2, Wl, labels, gate_mask, N, way, shot, K,
+                              C, P, u1, u2, u3, s.coef, stream));
+    PROBED(DENET_K_PE_BWD_PARAMS,
+           denet_pe_bwd_params(u1, u2, u3, s.S, s.hidden, s.pool, dWn_src, labels, weight_mask, N, way, shot, K, C,
+                               P, dW1, db1, dW2, db2, dWl, dbl, dweight, stream));
     PROBED(DENET_K_MASKED_SUM_BWD, denet_masked_sum_bwd(s.mask, s.coef, B, C, P, dFs, feat_dtype, stream));
     return DENET_OK;
 }

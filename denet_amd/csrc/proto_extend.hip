@@ -460,6 +460,49 @@ extern "C" int64_t denet_proto_extend_bwd_workspace(int64_t N, int64_t way, int6
     return (3 * N * way * shot * C + N * K * C) * 4;
 }
 
+// The three launches of K2b, separately callable so that the fused step can time each one.
+int denet_pe_bwd_reduce(const float* dWn_part, int64_t n_part, int64_t N, int64_t K, int64_t C, float* dWn,
+                        void* stream) {
+    const int64_t per_n = K * C;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((per_n / 4 + 255) / 256), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, dWn_part, (int)n_part, per_n, dWn);
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+int denet_pe_bwd_chain(const float* dWn, const float* S, const float* cnt, const float* hidden, const float* gate,
+                       const float* W1, const float* W2, const float* Wl, const int64_t* labels,
+                       const float* gate_mask, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
+                       int64_t P, float* u1, float* u2, float* u3, float* coef, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(C * 8 + CH_THREADS * 8 + C) * 4;
+#define CH_LAUNCH(CC, CHK)                                                                                   \
+    hipLaunchKernelGGL((proto_extend_bwd_chain_kernel<CC, CHK>), dim3((unsigned)(N * way)), dim3(CH_THREADS),  \
+                       lds, st, dWn, 1, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, (int)way,        \
+                       (int)shot, (int)K, (float)P, u1, u2, u3, coef)
+    switch (C) {
+        case 64: CH_LAUNCH(64, 8); break;
+        case 256: CH_LAUNCH(256, 16); break;
+        default: return DENET_E_UNSUPPORTED;
+    }
+#undef CH_LAUNCH
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+int denet_pe_bwd_params(const float* u1, const float* u2, const float* u3, const float* S, const float* hidden,
+                        const float* pool, const float* dWn, const int64_t* labels, const float* weight_mask,
+                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P, float* dW1,
+                        float* db1, float* dW2, float* db2, float* dWl, float* dbl, float* dweight, void* stream) {
+    const int64_t B = N * way * shot;
+    const unsigned gx = (unsigned)((C / WG_ROWS) > K ? (C / WG_ROWS) : K);
+    hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, (hipStream_t)stream, u1, u2, u3, S,
+                       hidden, pool, dWn, 1, labels, weight_mask, (int)N, (int)way, (int)B, (int)K, (int)C, (float)P,
+                       dW1, db1, dW2, db2, dWl, dbl, dweight);
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
 extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, const float* S, const float* cnt,
                                       const float* hidden, const float* gate, const float* pool,
                                       const float* W1, const float* W2, const float* Wl, const int64_t* labels,
@@ -480,34 +523,16 @@ extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, con
     float* u2 = u1 + B * C;
     float* u3 = u2 + B * C;
     float* dWn = u3 + B * C;                      // [N,K,C] tile-reduced
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
     if (n_part > 1) {
-        const int64_t per_n = K * C;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((per_n / 4 + 255) / 256), (unsigned)N), dim3(256), 0,
-                           st, dWn_part, (int)n_part, per_n, dWn);
-        DENET_CHECK_LAUNCH();
+        if ((rc = denet_pe_bwd_reduce(dWn_part, n_part, N, K, C, dWn, stream))) return rc;
         dWn_part = dWn;
-        n_part = 1;
     }
-    const size_t lds = (size_t)(C * 8 + CH_THREADS * 8 + C) * 4;
-#define CH_LAUNCH(CC, CHK)                                                                                   \
-    hipLaunchKernelGGL((proto_extend_bwd_chain_kernel<CC, CHK>), dim3((unsigned)(N * way)), dim3(CH_THREADS),  \
-                       lds, st, dWn_part, (int)n_part, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask,   \
-                       (int)way, (int)shot, (int)K, (float)P, u1, u2, u3, coef)
-    switch (C) {
-        case 64: CH_LAUNCH(64, 8); break;
-        case 128: CH_LAUNCH(128, 16); break;
-        case 256: CH_LAUNCH(256, 16); break;
-        default: return DENET_E_UNSUPPORTED;
-    }
-#undef CH_LAUNCH
-    DENET_CHECK_LAUNCH();
-    const unsigned gx = (unsigned)((C / WG_ROWS) > K ? (C / WG_ROWS) : K);
-    hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, st, u1, u2, u3, S, hidden,
-                       pool, dWn_part, (int)n_part, labels, weight_mask, (int)N, (int)way, (int)B, (int)K,
-                       (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight);
-    DENET_CHECK_LAUNCH();
-    return DENET_OK;
+    if ((rc = denet_pe_bwd_chain(dWn_part, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, N, way, shot, K, C,
+                                 P, u1, u2, u3, coef, stream)))
+        return rc;
+    return denet_pe_bwd_params(u1, u2, u3, S, hidden, pool, dWn_part, labels, weight_mask, N, way, shot, K, C, P,
+                               dW1, db1, dW2, db2, dWl, dbl, dweight, stream);
 }
 
 // dWn[n] = sum over position tiles of the slabs K3b wrote, as a tensor (the gradient of

@@ -223,8 +223,10 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
 #define DENET_K_FOCAL_FWD        6
 #define DENET_K_LOSS_FINALIZE    7
 #define DENET_K_CLASSIFY_BWD     8
-#define DENET_K_PROTO_EXTEND_BWD 9   /* two launches: chain + parameter gradients */
+#define DENET_K_PE_BWD_CHAIN     9   /* K2b: per-group chain of transposed mat-vecs            */
 #define DENET_K_MASKED_SUM_BWD   10
+#define DENET_K_PE_BWD_REDUCE    11  /* K2b: sum of the classifier's per-tile dWn slabs         */
+#define DENET_K_PE_BWD_PARAMS    12  /* K2b: parameter gradients                                */
 typedef struct denet_probe {
     int32_t which;      /* DENET_K_* */
     int32_t reserved;
