@@ -22,6 +22,7 @@ _SIGS = {
     "denet_mask_resize": "plllllpp",
     "denet_masked_sum_fwd": "piplllp",
     "denet_masked_sum_bwd": "pplllpi",
+    "denet_masked_pool_fwd": "pip" "llllll" "ppp",
     "denet_proto_extend_fwd": "pppppppppppp" "llllll" "ppppp",
     "denet_proto_extend_bwd": "pl" "ppppp" "ppp" "ppp" "llllll" "pppppppp" "pl",
     "denet_classify_fwd": "pipp" "lllll" "i" "pp",
@@ -40,7 +41,7 @@ _SIGS = {
     "denet_binary_iou_counts": "pp" "ll" "p",
     "denet_binary_iou_counts_fused": "pp" "lllll" "p",
     "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl" "h",
-    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllllll" "pp" "ppppppp" "pl" "h",
+    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllllll" "pp" "ppppppp" "pi" "pl" "h",
 }
 _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
@@ -59,9 +60,10 @@ class Probe(ctypes.Structure):
                 ("start", ctypes.c_void_p), ("stop", ctypes.c_void_p)]
 
 
-KERNEL_IDS = {"mask_resize": 1, "masked_sum_fwd": 2, "proto_extend_fwd": 3, "classify_fwd": 4, "wce_fwd": 5,
-              "focal_fwd": 6, "loss_finalize": 7, "classify_bwd": 8, "pe_bwd_reduce": 11, "pe_bwd_chain": 9,
-              "pe_bwd_params": 12, "masked_sum_bwd": 10}
+# the launches of the fused step (include/denet_hip.h, DENET_K_*)
+KERNEL_IDS = {"masked_pool_fwd": 2, "proto_extend_fwd": 3, "classify_fwd": 4, "loss_pair_fwd": 5,
+              "loss_finalize": 7, "bwd_dwn": 8, "bwd_chain_dfq": 9, "bwd_params_dfs": 10}
+GRAD_DEFER_LOSSES = 2
 
 EXPORTS = sorted(list(_SIGS) + list(_NOSTREAM))
 

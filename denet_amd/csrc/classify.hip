@@ -20,36 +20,36 @@
 //     N * ceil(P/64) * 4 waves of parallelism at batch 8.
 // fp32 in, fp32 accumulate: bit-for-bit an fmaf chain per output (guide §3).
 #include "denet_common.hpp"
+#include "dev_classify.hpp"
 
-#define CL_TP 64          // positions per block
-#define CL_LD 66          // LDS row stride of a 64-wide tile (even: 8-byte reads)
-
-typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
-typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
-
-template <typename T>
-__device__ __forceinline__ void load2(const T* p, bool ok0, bool ok1, bool fast, float& a, float& b);
+// Two adjacent positions of one channel row.  Every load is UNCONDITIONAL (out-of-range lanes read a
+// clamped, valid address and are zeroed by a select afterwards): a load inside a branch makes the
+// compiler drain vmcnt at the join, which turns a burst of 32 independent loads into 32 round trips.
+template <typename T, bool FAST>
+__device__ __forceinline__ void load2(const T* row, int pa, int P, float& a, float& b);
 template <>
-__device__ __forceinline__ void load2<float>(const float* p, bool ok0, bool ok1, bool fast, float& a, float& b) {
-    if (fast) {
-        f32x2_u v = *reinterpret_cast<const f32x2_u*>(p);
-        a = v[0]; b = v[1];
-    } else {
-        a = ok0 ? p[0] : 0.f;
-        b = ok1 ? p[1] : 0.f;
-    }
+__device__ __forceinline__ void load2<float, true>(const float* row, int pa, int P, float& a, float& b) {
+    const f32x2_u v = *reinterpret_cast<const f32x2_u*>(row + pa);
+    a = v[0]; b = v[1];
 }
 template <>
-__device__ __forceinline__ void load2<unsigned short>(const unsigned short* p, bool ok0, bool ok1, bool fast,
-                                                     float& a, float& b) {
-    if (fast) {
-        u16x2_u v = *reinterpret_cast<const u16x2_u*>(p);
-        a = bf16_to_f32(v[0]); b = bf16_to_f32(v[1]);
-    } else {
-        a = ok0 ? bf16_to_f32(p[0]) : 0.f;
-        b = ok1 ? bf16_to_f32(p[1]) : 0.f;
-    }
+__device__ __forceinline__ void load2<float, false>(const float* row, int pa, int P, float& a, float& b) {
+    const float x = row[min(pa, P - 1)], y = row[min(pa + 1, P - 1)];
+    a = pa < P ? x : 0.f;
+    b = pa + 1 < P ? y : 0.f;
+}
+template <>
+__device__ __forceinline__ void load2<unsigned short, true>(const unsigned short* row, int pa, int P, float& a,
+                                                            float& b) {
+    const u16x2_u v = *reinterpret_cast<const u16x2_u*>(row + pa);
+    a = bf16_to_f32(v[0]); b = bf16_to_f32(v[1]);
+}
+template <>
+__device__ __forceinline__ void load2<unsigned short, false>(const unsigned short* row, int pa, int P, float& a,
+                                                             float& b) {
+    const unsigned short x = row[min(pa, P - 1)], y = row[min(pa + 1, P - 1)];
+    a = pa < P ? bf16_to_f32(x) : 0.f;
+    b = pa + 1 < P ? bf16_to_f32(y) : 0.f;
 }
 
 template <typename T, int RT, int NLD>
@@ -66,16 +66,25 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     const int cper = C >> 2;                       // channels per wave: 16, 32, 64 or 128
     const int cbeg = wave * cper;
     const int pa = p0 + 2 * j;
-    const bool ok0 = pa < P, ok1 = pa + 1 < P;
-    const bool fast = (p0 + CL_TP <= P);
-    const T* fq = Fq + (int64_t)n * C * P + pa;
+    const bool fast = (p0 + CL_TP <= P);           // block-uniform: only the last tile of an episode is partial
+    const T* fq = Fq + (int64_t)n * C * P;
     // The streamed operand first: up to 64 channels (32 k-steps, 16 KB per wave) of Fq go in flight
     // before anything else, so the Wn staging below hides under their latency.
     STAMP(0);
     constexpr int chunk = 2 * NLD;                 // channels per pass of this wave (== cper: C is 64 or 256)
     float b0[NLD], b1[NLD];
+#ifdef DENET_DIAG_NO_FQ
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) load2<T>(fq + (int64_t)(cbeg + 2 * u + hh) * P, ok0, ok1, fast, b0[u], b1[u]);
+    for (int u = 0; u < NLD; ++u) { b0[u] = (float)u; b1[u] = 1.f; }
+#else
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) load2<T, true>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) load2<T, false>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
+    }
+#endif
 
     // stage Wn[n] -> LDS [K][C+1]: 16-byte loads, all of a thread's loads issued before the first store
     {
@@ -87,7 +96,11 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i4 = base + u * 256 + tid;
-                if (i4 < nv) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)i4 * 4);
+#ifdef DENET_DIAG_NO_WN
+                v[u] = f32x4{1.f, 2.f, 3.f, 4.f};
+#else
+                v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(i4, nv - 1) * 4);
+#endif
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         if (c + chunk < cbeg + cper) {             // only if a wave owns more than one chunk
 #pragma unroll
             for (int u = 0; u < NLD; ++u)
-                load2<T>(fq + (int64_t)(c + chunk + 2 * u + hh) * P, ok0, ok1, fast, b0[u], b1[u]);
+                load2<T, false>(fq + (int64_t)(c + chunk + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
         }
     }
     STAMP(2);
@@ -190,167 +203,6 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         dst[P] = fg;
     }
     STAMP(4);
-}
-
-// ---------------------------------------------------------------------------
-// K3b: backward.  One block per (episode, 64-position tile):
-//   dL[k][p]   = scale[n] * (dlog_a + dlog_b)                     -> LDS
-//   dFq[c][p]  = sum_k Wn[k][c] * dL[k][p]                        (A = Wn^T from L2, B = dL from LDS)
-//   dWn_part[tile][k][c] = sum_{p in tile} dL[k][p] * Fq[c][p]    (A = dL from LDS, B = Fq^T: each
-//        lane holds 32 consecutive positions of one channel row in registers; the MFMA k index of
-//        step s is position 32*(lane>>5) + s for both operands)
-// The partial dWn slabs are summed by K2b (no float atomics: deterministic).
-// ---------------------------------------------------------------------------
-template <typename T, int RT>
-__global__ __launch_bounds__(256) void classify_bwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
-                                                          const float* __restrict__ dlog_a,
-                                                          const float* __restrict__ dlog_b,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ gmul, int K, int C, int P,
-                                                          int n_part, T* __restrict__ dFq,
-                                                          float* __restrict__ dWn_part) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // dL [KP][CL_LD]
-    const int n = blockIdx.y, tile = blockIdx.x, p0 = tile * CL_TP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int KP = (K + 1) & ~1;
-    const float sc = (scale ? scale[n] : 1.f) * (gmul ? gmul[0] : 1.f);
-    const float* wn = Wn + (int64_t)n * K * C;
-    const bool fast = (p0 + CL_TP <= P);
-    const int nct = C >> 5;                      // 32-channel tiles: 2 (C=64) or 8 (C=256); <= 2 per wave
-    constexpr int NA = RT * 16;
-    // With K <= 32 every global operand of this block fits in registers, so ALL of them are
-    // requested before the first wait: the block then pays one memory latency, not five.
-    constexpr bool PRE = (RT == 1);
-    float av[2][PRE ? NA : 1];
-    float fv[2][PRE ? 32 : 1];
-
-    auto load_av = [&](int ct, float* dst) {
-#pragma unroll
-        for (int u = 0; u < NA; ++u) {
-            const int kk = 2 * u + hh;
-            dst[u] = kk < K ? wn[(int64_t)kk * C + ct * 32 + j] : 0.f;
-        }
-    };
-    auto load_fv = [&](int ct, float* dst) {
-        const int pb = p0 + 32 * hh;
-        const T* src = Fq + ((int64_t)n * C + ct * 32 + j) * P + pb;
-        if (fast) {
-            if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)src + 4 * m);
-                    dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 32; ++s) dst[s] = FeatIO<T>::load(src + s);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 32; ++s) dst[s] = (pb + s < P) ? FeatIO<T>::load(src + s) : 0.f;
-        }
-    };
-    if constexpr (PRE) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ct = wave + 4 * i;
-            if (ct < nct) {
-                if (dFq != nullptr) load_av(ct, av[i]);
-                if (dWn_part != nullptr) load_fv(ct, fv[i]);
-            }
-        }
-    }
-
-#pragma unroll 1
-    for (int base = 0; base < KP * CL_TP; base += 256 * 6) {
-        float va[6], vb[6];
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int idx = base + u * 256 + tid;
-            const int k = idx >> 6, col = idx & 63;
-            const int p = p0 + col;
-            va[u] = 0.f; vb[u] = 0.f;
-            if (idx < KP * CL_TP && k < K && p < P) {
-                const int64_t gi = ((int64_t)n * K + k) * P + p;
-                va[u] = dlog_a[gi];
-                if (dlog_b) vb[u] = dlog_b[gi];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int idx = base + u * 256 + tid;
-            if (idx < KP * CL_TP) sm[(idx >> 6) * CL_LD + (idx & 63)] = (va[u] + vb[u]) * sc;
-        }
-    }
-    __syncthreads();
-
-    // ---- dFq ----
-    if (dFq != nullptr) {
-        const int pa = p0 + 2 * j;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ct = wave + 4 * i;
-            if (ct >= nct) continue;
-            const int c0 = ct * 32;
-            f32x16 a0, a1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-            float avl[NA];
-            if constexpr (!PRE) load_av(ct, avl);
-#pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int kk = 2 * u + hh;
-                if (2 * u < KP) {
-                    const float a = PRE ? av[i][PRE ? u : 0] : avl[u];
-                    const f32x2 b = *reinterpret_cast<const f32x2*>(sm + kk * CL_LD + 2 * j);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], a1, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                T* dst = dFq + ((int64_t)n * C + c) * P + pa;
-                if (pa < P) FeatIO<T>::store(dst, a0[e]);
-                if (pa + 1 < P) FeatIO<T>::store(dst + 1, a1[e]);
-            }
-        }
-    }
-
-    // ---- dWn partial ----
-    if (dWn_part != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ct = wave + 4 * i;
-            if (ct >= nct) continue;
-            const int c0 = ct * 32;
-            float fvl[32];
-            if constexpr (!PRE) load_fv(ct, fvl);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int row = 32 * rt + j;
-                const bool ok = row < K;
-                const float* arow = sm + (ok ? row : 0) * CL_LD + 32 * hh;
-                f32x16 acc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    float a = arow[s];
-                    a = ok ? a : 0.f;
-                    const float bq = PRE ? fv[i][PRE ? s : 0] : fvl[s];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (kr < K)
-                        dWn_part[(((int64_t)n * n_part + tile) * K + kr) * C + c0 + j] = acc[e];
-                }
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -468,11 +320,11 @@ static int launch_classify_bwd(const T* Fq, const float* Wn, const float* da, co
                                const float* gmul, int64_t N, int64_t K, int64_t C, int64_t P, T* dFq, float* dWn_part, hipStream_t st) {
     const int RT = (int)((K + 31) / 32);
     const int n_part = (int)denet_classify_bwd_parts(P);
-    const size_t lds = (size_t)((K + 1) & ~1) * CL_LD * 4;
+    const size_t lds = CLS_BWD_LDS(K);
     dim3 grid((unsigned)n_part, (unsigned)N), block(256);
-#define CL_BWD(R)                                                                                          \
-    hipLaunchKernelGGL((classify_bwd_kernel<T, R>), grid, block, lds, st, Fq, Wn, da, db, scale, gmul, (int)K, \
-                       (int)C, (int)P, n_part, dFq, dWn_part)
+    ClsBwdArgs g{Fq, Wn, da, db, scale, gmul, nullptr, 0, (int)N, (int)K, (int)C, (int)P, n_part, dFq, dWn_part,
+                 nullptr};
+#define CL_BWD(R) hipLaunchKernelGGL((classify_bwd_kernel<T, R>), grid, block, lds, st, g)
     switch (RT) {
         case 1: CL_BWD(1); break;
         case 2: CL_BWD(2); break;

@@ -98,14 +98,20 @@ int denet_ensure_dynamic_lds(const void* kernel, size_t bytes);
 // The three launches of K2b (proto_extend.hip), separately callable by the fused step.
 int denet_pe_bwd_reduce(const float* dWn_part, int64_t n_part, int64_t N, int64_t K, int64_t C, float* dWn,
                         void* stream);
-int denet_pe_bwd_chain(const float* dWn, const float* S, const float* cnt, const float* hidden, const float* gate,
+int denet_pe_bwd_chain(const float* dWn, int64_t n_part, const float* S, const float* cnt, const float* hidden, const float* gate,
                        const float* W1, const float* W2, const float* Wl, const int64_t* labels,
                        const float* gate_mask, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
                        int64_t P, float* u1, float* u2, float* u3, float* coef, void* stream);
 int denet_pe_bwd_params(const float* u1, const float* u2, const float* u3, const float* S, const float* hidden,
-                        const float* pool, const float* dWn, const int64_t* labels, const float* weight_mask,
-                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P, float* dW1,
+                        const float* pool, const float* dWn, int64_t n_part, const int64_t* labels,
+                        const float* weight_mask, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P, float* dW1,
                         float* db1, float* dW2, float* db2, float* dWl, float* dbl, float* dweight, void* stream);
+
+// CE + focal in one launch (upsample_loss.hip), used by the fused step.
+int denet_loss_pair_fwd(const float* logits, const int64_t* Yq_full, const float* wgt, const float* logits_binary,
+                        const int64_t* Yq, int64_t N, int64_t NB, int64_t K, int64_t h, int64_t w, int64_t H,
+                        int64_t W, float alpha, float gamma, float* part_k, float* part_p, float* da, float* db,
+                        void* stream);
 
 // Diagnostic builds only (scripts/diag): phase stamps of block 0 / thread 0 into a debug buffer.
 #ifdef DENET_STAMPS

@@ -1,0 +1,203 @@
+// Device bodies of K0/K1/K1b, shared by the stand-alone kernels (masked_sum.hip) and the fused
+// step kernels (head_step.hip).
+#pragma once
+#include "denet_common.hpp"
+
+// ---------------------------------------------------------------------------
+// K1: S[b,c] = sum_p mask[b,p] * Fs[b,c,p]
+// ---------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    typedef f32x4 type;
+    static __device__ __forceinline__ float dot(const type& v, const float* m) {
+        return v[0] * m[0] + v[1] * m[1] + v[2] * m[2] + v[3] * m[3];
+    }
+};
+template <> struct Vec16<unsigned short> {
+    static constexpr int N = 8;
+    typedef u16x8 type;
+    static __device__ __forceinline__ float dot(const type& v, const float* m) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += bf16_to_f32(v[e]) * m[e];
+        return a;
+    }
+};
+
+// Body of K1 for block (cblk, b): `sm` [P] floats of LDS.  With Ys != nullptr the mask is gathered
+// here from the int64 label map (K0 fused: nearest resize, model/common.py:189-190) and the block
+// with cblk == 0 also writes mask[b,:] and cnt[b] for the backward pass; otherwise it is read from `mask`.
+template <typename T>
+__device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, const int64_t* __restrict__ Ys,
+                                                    float* __restrict__ mask, float* __restrict__ cnt,
+                                                    float* __restrict__ S, int C, int P, int rows_per_block, int H,
+                                                    int W, int h, int w, int b, int cblk, float* sm) {
+    const int c0 = cblk * rows_per_block;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mrow = mask + (int64_t)b * P;
+    if (Ys != nullptr) {
+        const float sy = nearest_scale(H, h), sx = nearest_scale(W, w);
+        const int64_t* src = Ys + (int64_t)b * H * W;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const int y = p / w, x = p - y * w;
+            const float m = (float)src[(int64_t)nearest_src(y, sy, H) * W + nearest_src(x, sx, W)];
+            sm[p] = m;
+            acc += m;
+            if (cblk == 0) mrow[p] = m;
+        }
+        if (cblk == 0) {
+            // every partial sum is a small integer: exact in any order
+            acc = wave_sum(acc);
+            float* red = sm + ((P + 3) & ~3);
+            if (lane == 0) red[wave] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    } else {
+        // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
+        // latency once per iteration)
+#pragma unroll 8
+        for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
+    }
+    __syncthreads();
+
+    constexpr int V = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
+    if ((P / V) <= NV * 64) {
+        // Short rows (P <= 2048 fp32 / 4096 bf16 elements): every load of TWO rows is issued before the
+        // first use, all of them unconditional (clamped index, value selected afterwards), so a wave
+        // pays one memory round trip per pair of rows instead of three per row.
+        for (int r = wave; r < rows_per_block; r += 8) {
+            float accs[2];
+            vec_t v[2][NV];
+            float hv[2], tv[2];
+            int heads[2], nvecs[2];
+            bool live[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = c0 + r + 4 * q;
+                live[q] = (r + 4 * q < rows_per_block) && (c < C);
+                const T* row = Fs + ((int64_t)b * C + (live[q] ? c : c0)) * P;
+                const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
+                int head = mis ? V - mis : 0;
+                if (head > P) head = P;
+                const int nvec = (P - head) / V;
+                heads[q] = head; nvecs[q] = nvec;
+                const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
+                hv[q] = FeatIO<T>::load(row + min(lane, P - 1));
+                tv[q] = FeatIO<T>::load(row + min(head + nvec * V + lane, P - 1));
+#pragma unroll
+                for (int u = 0; u < NV; ++u) v[q][u] = rv[min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int head = heads[q], nvec = nvecs[q], t0 = head + nvec * V;
+                float acc = (lane < head) ? hv[q] * sm[min(lane, P - 1)] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int i = lane + 64 * u;
+                    const float d = Vec16<T>::dot(v[q][u], sm + head + min(i, nvec > 0 ? nvec - 1 : 0) * V);
+                    acc += (i < nvec) ? d : 0.f;
+                }
+                acc += (t0 + lane < P) ? tv[q] * sm[min(t0 + lane, P - 1)] : 0.f;
+                accs[q] = wave_sum(acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (live[q] && lane == 0) S[(int64_t)b * C + c0 + r + 4 * q] = accs[q];
+        }
+        return;
+    }
+    for (int r = wave; r < rows_per_block; r += 4) {
+        const int c = c0 + r;
+        if (c >= C) break;
+        const T* row = Fs + ((int64_t)b * C + c) * P;
+        const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
+        int head = mis ? V - mis : 0;
+        if (head > P) head = P;
+        const float hv = FeatIO<T>::load(row + min(lane, P - 1));
+        float acc = (lane < head) ? hv * sm[min(lane, P - 1)] : 0.f;
+        const int nvec = (P - head) / V;
+        const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
+        const int t0 = head + nvec * V;
+        const float tv = FeatIO<T>::load(row + min(t0 + lane, P - 1));
+#pragma unroll 4
+        for (int i = lane; i < nvec; i += 64) {
+            vec_t v = rv[i];
+            acc += Vec16<T>::dot(v, sm + head + i * V);
+        }
+        acc += (t0 + lane < P) ? tv * sm[min(t0 + lane, P - 1)] : 0.f;
+        acc = wave_sum(acc);
+        if (lane == 0) S[(int64_t)b * C + c] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
+                                                            const int64_t* __restrict__ Ys,
+                                                            float* __restrict__ mask, float* __restrict__ cnt,
+                                                            float* __restrict__ S, int C, int P,
+                                                            int rows_per_block, int H, int W, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [P] (+ 4)
+    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, blockIdx.y, blockIdx.x, sm);
+}
+
+// ---------------------------------------------------------------------------
+// K1b: dFs[b,c,p] = mask[b,p] * coef[b,c]
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ mask, const float* __restrict__ coef,
+                                                    T* __restrict__ dFs, int C, int P, int rows_per_block, int b,
+                                                    int cblk, float* sm) {
+    const int c0 = cblk * rows_per_block;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* mrow = mask + (int64_t)b * P;
+    // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
+    // latency once per iteration)
+#pragma unroll 8
+    for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
+    __syncthreads();
+
+    constexpr int V = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    for (int r = wave; r < rows_per_block; r += 4) {
+        const int c = c0 + r;
+        if (c >= C) break;
+        const float k = coef[(int64_t)b * C + c];
+        T* row = dFs + ((int64_t)b * C + c) * P;
+        const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
+        int head = mis ? V - mis : 0;
+        if (head > P) head = P;
+        if (lane < head) FeatIO<T>::store(row + lane, k * sm[lane]);
+        const int nvec = (P - head) / V;
+        vec_t* rv = reinterpret_cast<vec_t*>(row + head);
+#pragma unroll 4
+        for (int i = lane; i < nvec; i += 64) {
+            const float* m = sm + head + i * V;
+            vec_t v;
+            if constexpr (V == 4) {
+                v[0] = k * m[0]; v[1] = k * m[1]; v[2] = k * m[2]; v[3] = k * m[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(k * m[e]);
+            }
+            rv[i] = v;
+        }
+        const int t0 = head + nvec * V;
+        if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[t0 + lane]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __restrict__ mask,
+                                                            const float* __restrict__ coef,
+                                                            T* __restrict__ dFs, int C, int P,
+                                                            int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    masked_sum_bwd_body<T>(mask, coef, dFs, C, P, rows_per_block, blockIdx.y, blockIdx.x, sm);
+}
+

@@ -14,10 +14,10 @@
 // Backward (transposed) mat-vec layout: one thread per column, the row loop
 // split over 512/C thread groups; loads are coalesced across columns.
 #include "denet_common.hpp"
+#include "dev_proto_extend.hpp"
 
 #define PE_THREADS 512
 
-#define PE_EPS 1e-3f      // model/common.py:170
 
 // ---------------------------------------------------------------------------
 // Forward.  1024 threads = 16 waves; a wave covers 4 weight rows per step, 16 lanes per row
@@ -179,243 +179,6 @@ __global__ __launch_bounds__(PF_THREADS) void proto_extend_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Backward, stage A: per-group chain of three transposed mat-vecs for up to 8 images at a time
-// (vin laid out [C][8] in LDS, zero padded):   y[s][i] = sum_o W[o][i] * vin[o][s]
-// 512 threads: thread (i = tid % C, sp = tid / C) owns column i for R = C*C/512 consecutive rows,
-// taken in chunks of CH rows.  As in the forward kernel the three mat-vecs are one sequence of
-// chunks whose loads run through a 4-slot register ring three chunks ahead of the FMAs.
-// ---------------------------------------------------------------------------
-#define CH_THREADS 512
-
-template <int CH>
-__device__ __forceinline__ void cols_chunk(const float (&wr)[CH], const float* vin /*[C][8]*/, int o0, float (&acc)[8]) {
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8 + 4);
-        acc[0] += wr[t] * v0[0]; acc[1] += wr[t] * v0[1]; acc[2] += wr[t] * v0[2]; acc[3] += wr[t] * v0[3];
-        acc[4] += wr[t] * v1[0]; acc[5] += wr[t] * v1[1]; acc[6] += wr[t] * v1[2]; acc[7] += wr[t] * v1[3];
-    }
-}
-
-// sum of the splits' partial results for (column i, image s)
-__device__ __forceinline__ float cols_total(const float* red, int C, int i, int s) {
-    const int nsplit = CH_THREADS / C;
-    float t = 0.f;
-    for (int q = 0; q < nsplit; ++q) t += red[(q * 8 + s) * C + i];
-    return t;
-}
-
-template <int C, int CH>
-__global__ __launch_bounds__(CH_THREADS) void proto_extend_bwd_chain_kernel(
-    const float* __restrict__ dWn_part, int n_part, const float* __restrict__ S,
-    const float* __restrict__ cnt, const float* __restrict__ hidden, const float* __restrict__ gate,
-    const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wl,
-    const int64_t* __restrict__ labels, const float* __restrict__ gate_mask, int way, int shot, int K,
-    float Pf, float* __restrict__ u1 /*dpre1 [B,C]*/, float* __restrict__ u2 /*dz [B,C]*/,
-    float* __restrict__ u3 /*dproto [B,C]*/, float* __restrict__ coef /*[B,C]*/) {
-    constexpr int R = C * C / CH_THREADS;        // rows per thread
-    constexpr int NCH = R / CH, T = 3 * NCH;     // chunks per mat-vec, chunks in all
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* vin = sm;                 // [C][8]
-    float* red = vin + C * 8;        // [nsplit*8][C]  (nsplit*C = 512)
-    float* dpool = red + CH_THREADS * 8;   // [C]
-    const int grp = blockIdx.x;
-    const int n = grp / way, j = grp - n * way;
-    const int64_t b0 = (int64_t)grp * shot;
-    const int tid = threadIdx.x;
-    const int ci = tid % C, sp = tid / C;
-    const int ns = shot;
-
-    float ring[4][CH];
-    auto issue = [&](int t, float (&dst)[CH]) {
-        const float* W = (t < NCH) ? Wl : (t < 2 * NCH ? W2 : W1);
-        const int ch = t % NCH;
-        const float* p = W + (int64_t)(sp * R + ch * CH) * C + ci;
-#pragma unroll
-        for (int q = 0; q < CH; ++q) dst[q] = p[(int64_t)q * C];
-    };
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (t < T) issue(t, ring[t]);
-
-    // dproto[s] = dWn[n, label_j] / shot for every shot (mean backward), if this way owns the row
-    const int64_t* lab = labels + (int64_t)n * way;
-    const int64_t mine = lab[j];
-    bool win = mine >= 0 && mine < K;
-    for (int jj = j + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
-    for (int c = tid; c < C; c += CH_THREADS) {
-        float t = 0.f;
-        if (win) {
-            const float* src = dWn_part + (((int64_t)n * n_part) * K + mine) * C + c;
-#pragma unroll 8
-            for (int q = 0; q < n_part; ++q) t += src[(int64_t)q * K * C];
-        }
-        t /= (float)shot;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) vin[c * 8 + s] = (s == 0) ? t : 0.f;
-        for (int s = 0; s < shot; ++s) u3[(b0 + s) * C + c] = t;
-    }
-    __syncthreads();
-
-    float acc[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (t + 3 < T) issue(t + 3, ring[(t + 3) & 3]);
-        const int mv = t / NCH, ch = t % NCH;
-        cols_chunk<CH>(ring[t & 3], vin, sp * R + ch * CH, acc);
-        if (ch == NCH - 1) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { red[(sp * 8 + s) * C + ci] = acc[s]; acc[s] = 0.f; }
-            __syncthreads();
-            if (mv == 0) {
-                // dpool[i] = sum_o Wl[o][i] * dproto[o]   (identical for every shot of the group)
-                for (int i = tid; i < C; i += CH_THREADS) dpool[i] = cols_total(red, C, i, 0);
-                __syncthreads();
-                // dz = dpool * S/(cnt+eps) * g(1-g) * gate_mask      (pool = g*S/(cnt+eps))
-                for (int idx = tid; idx < C * 8; idx += CH_THREADS) {
-                    const int c = idx >> 3, s = idx & 7;
-                    float dz = 0.f;
-                    if (s < ns) {
-                        const int64_t gi = (b0 + s) * C + c;
-                        const float g = gate[gi];
-                        const float den = cnt[b0 + s] + PE_EPS;
-                        dz = dpool[c] * S[gi] / den * g * (1.f - g);
-                        if (gate_mask) dz *= gate_mask[gi];
-                        u2[gi] = dz;
-                    }
-                    vin[idx] = dz;
-                }
-            } else if (mv == 1) {
-                // dhidden = W2^T dz ; dpre1 = dhidden * (hidden > 0)
-                for (int idx = tid; idx < C * 8; idx += CH_THREADS) {
-                    const int c = idx >> 3, s = idx & 7;
-                    float d = 0.f;
-                    if (s < ns) {
-                        const int64_t gi = (b0 + s) * C + c;
-                        d = hidden[gi] > 0.f ? cols_total(red, C, c, s) : 0.f;
-                        u1[gi] = d;
-                    }
-                    vin[idx] = d;
-                }
-            } else {
-                // datt = W1^T dpre1 ; coef = dpool*g/(cnt+eps) + datt/P
-                for (int idx = tid; idx < C * ns; idx += CH_THREADS) {
-                    const int s = idx / C, c = idx - s * C;
-                    const int64_t gi = (b0 + s) * C + c;
-                    const float den = cnt[b0 + s] + PE_EPS;
-                    coef[gi] = dpool[c] * gate[gi] / den + cols_total(red, C, c, s) / Pf;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// dWn[n,k,c] = sum over position tiles of the partial slabs K3b wrote (fixed order: deterministic)
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int n_part, int64_t per_n,
-                                                          float* __restrict__ out) {
-    const int n = blockIdx.y;
-    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= per_n) return;
-    const float* src = part + (int64_t)n * n_part * per_n + i4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 9
-    for (int q = 0; q < n_part; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)q * per_n);
-        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
-    }
-    *reinterpret_cast<f32x4*>(out + (int64_t)n * per_n + i4) = a;
-}
-
-// ---------------------------------------------------------------------------
-// Backward, stage B: parameter gradients (sums over all B support images).
-//   blockIdx.y = 0: dW1 = dpre1^T att   1: dW2 = dz^T hidden   2: dWl = dproto^T pool
-//   blockIdx.y = 3: dweight[k] = sum_n [k not novel in n] weight_mask[n,k] * dWn[n,k]
-// ---------------------------------------------------------------------------
-#define WG_ROWS 4
-__global__ __launch_bounds__(256) void proto_extend_bwd_params_kernel(
-    const float* __restrict__ u1, const float* __restrict__ u2, const float* __restrict__ u3,
-    const float* __restrict__ S, const float* __restrict__ hidden, const float* __restrict__ pool,
-    const float* __restrict__ dWn_part, int n_part, const int64_t* __restrict__ labels,
-    const float* __restrict__ weight_mask, int N, int way, int B, int K, int C, float Pf,
-    float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
-    float* __restrict__ dWl, float* __restrict__ dbl, float* __restrict__ dweight) {
-    const int which = blockIdx.y;
-    const int tid = threadIdx.x;
-    if (which == 3) {
-        // dweight[k,c] = sum over (n, tile) of the partial slabs, novel rows and dropped entries excluded.
-        // The 256 threads are C/4 float4 columns x (1024/C) groups that split the (n, tile) pairs.
-        __shared__ f32x4 redw[256];
-        const int k = blockIdx.x;
-        if (k >= K) return;
-        const int c4n = C >> 2;                 // float4 columns
-        const int ngrp = 256 / c4n;             // C=256 -> 4 groups
-        const int c4 = tid % c4n, grp = tid / c4n;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (grp < ngrp) {
-            const int pairs = N * n_part;
-            for (int n = 0; n < N; ++n) {
-                bool novel = false;
-                for (int jj = 0; jj < way; ++jj) novel = novel || (labels[(int64_t)n * way + jj] == k);
-                if (novel) continue;
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                const float* src = dWn_part + (((int64_t)n * n_part) * K + k) * C + c4 * 4;
-#pragma unroll 8
-                for (int q = grp; q < n_part; q += ngrp) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)q * K * C);
-                    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
-                }
-                if (weight_mask) {
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(weight_mask + ((int64_t)n * K + k) * C + c4 * 4);
-                    a[0] *= m[0]; a[1] *= m[1]; a[2] *= m[2]; a[3] *= m[3];
-                }
-                t[0] += a[0]; t[1] += a[1]; t[2] += a[2]; t[3] += a[3];
-            }
-            (void)pairs;
-        }
-        redw[tid] = t;
-        __syncthreads();
-        if (tid < c4n) {
-            f32x4 r = redw[tid];
-            for (int g2 = 1; g2 < ngrp; ++g2) {
-                const f32x4 v = redw[g2 * c4n + tid];
-                r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3];
-            }
-            *reinterpret_cast<f32x4*>(dweight + (int64_t)k * C + tid * 4) = r;
-        }
-        return;
-    }
-    const int o0 = blockIdx.x * WG_ROWS;
-    if (o0 >= C) return;
-    const float* U = which == 0 ? u1 : (which == 1 ? u2 : u3);
-    const float* V = which == 0 ? S : (which == 1 ? hidden : pool);
-    const float vs = which == 0 ? 1.f / Pf : 1.f;
-    float* dW = which == 0 ? dW1 : (which == 1 ? dW2 : dWl);
-    float* db = which == 0 ? db1 : (which == 1 ? db2 : dbl);
-    for (int i = tid; i < C; i += 256) {
-        float acc[WG_ROWS];
-#pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int b = 0; b < B; ++b) {
-            const float v = V[(int64_t)b * C + i];
-#pragma unroll
-            for (int r = 0; r < WG_ROWS; ++r) acc[r] += U[(int64_t)b * C + o0 + r] * v;
-        }
-#pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) dW[(int64_t)(o0 + r) * C + i] = acc[r] * vs;
-    }
-    if (tid < WG_ROWS) {
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += U[(int64_t)b * C + o0 + tid];
-        db[o0 + tid] = t;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
@@ -470,16 +233,19 @@ int denet_pe_bwd_reduce(const float* dWn_part, int64_t n_part, int64_t N, int64_
     return DENET_OK;
 }
 
-int denet_pe_bwd_chain(const float* dWn, const float* S, const float* cnt, const float* hidden, const float* gate,
+int denet_pe_bwd_chain(const float* dWn, int64_t n_part, const float* S, const float* cnt, const float* hidden, const float* gate,
                        const float* W1, const float* W2, const float* Wl, const int64_t* labels,
                        const float* gate_mask, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
                        int64_t P, float* u1, float* u2, float* u3, float* coef, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(C * 8 + CH_THREADS * 8 + C) * 4;
+    const size_t lds = PE_CHAIN_LDS(C);
+    PeChainArgs a{dWn, S, cnt, hidden, gate, W1, W2, Wl, gate_mask, labels, (int)n_part, (int)way, (int)shot,
+                  (int)K, (float)P, u1, u2, u3, coef};
 #define CH_LAUNCH(CC, CHK)                                                                                   \
+    if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(proto_extend_bwd_chain_kernel<CC, CHK>), lds)) \
+        return DENET_E_LAUNCH;                                                                               \
     hipLaunchKernelGGL((proto_extend_bwd_chain_kernel<CC, CHK>), dim3((unsigned)(N * way)), dim3(CH_THREADS),  \
-                       lds, st, dWn, 1, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, (int)way,        \
-                       (int)shot, (int)K, (float)P, u1, u2, u3, coef)
+                       lds, st, a)
     switch (C) {
         case 64: CH_LAUNCH(64, 8); break;
         case 256: CH_LAUNCH(256, 16); break;
@@ -491,14 +257,14 @@ int denet_pe_bwd_chain(const float* dWn, const float* S, const float* cnt, const
 }
 
 int denet_pe_bwd_params(const float* u1, const float* u2, const float* u3, const float* S, const float* hidden,
-                        const float* pool, const float* dWn, const int64_t* labels, const float* weight_mask,
-                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P, float* dW1,
+                        const float* pool, const float* dWn, int64_t n_part, const int64_t* labels,
+                        const float* weight_mask, int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P, float* dW1,
                         float* db1, float* dW2, float* db2, float* dWl, float* dbl, float* dweight, void* stream) {
     const int64_t B = N * way * shot;
-    const unsigned gx = (unsigned)((C / WG_ROWS) > K ? (C / WG_ROWS) : K);
-    hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, (hipStream_t)stream, u1, u2, u3, S,
-                       hidden, pool, dWn, 1, labels, weight_mask, (int)N, (int)way, (int)B, (int)K, (int)C, (float)P,
-                       dW1, db1, dW2, db2, dWl, dbl, dweight);
+    const unsigned gx = (unsigned)pe_params_gx((int)K, (int)C);
+    PeParamsArgs a{u1, u2, u3, S, hidden, pool, dWn, weight_mask, labels, (int)n_part, (int)N, (int)way, (int)B,
+                   (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight};
+    hipLaunchKernelGGL(proto_extend_bwd_params_kernel, dim3(gx, 4), dim3(256), 0, (hipStream_t)stream, a);
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -528,10 +294,10 @@ extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, con
         if ((rc = denet_pe_bwd_reduce(dWn_part, n_part, N, K, C, dWn, stream))) return rc;
         dWn_part = dWn;
     }
-    if ((rc = denet_pe_bwd_chain(dWn_part, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, N, way, shot, K, C,
+    if ((rc = denet_pe_bwd_chain(dWn_part, 1, S, cnt, hidden, gate, W1, W2, Wl, labels, gate_mask, N, way, shot, K, C,
                                  P, u1, u2, u3, coef, stream)))
         return rc;
-    return denet_pe_bwd_params(u1, u2, u3, S, hidden, pool, dWn_part, labels, weight_mask, N, way, shot, K, C, P,
+    return denet_pe_bwd_params(u1, u2, u3, S, hidden, pool, dWn_part, 1, labels, weight_mask, N, way, shot, K, C, P,
                                dW1, db1, dW2, db2, dWl, dbl, dweight, stream);
 }
 

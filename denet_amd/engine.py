@@ -42,6 +42,8 @@ class HeadStepEngine:
             self.grads[name] = self.grad_bucket[off:off + n].view(shp)
             off += n
         self._probe = None
+        self._deferred = False
+        self._have_focal = True
 
     def set_probe(self, which, start_event, stop_event):
         """Bracket kernel `which` (a name in _lib.KERNEL_IDS, or None) with HIP events."""
@@ -55,11 +57,16 @@ class HeadStepEngine:
         self._probe = p
 
     def forward(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
-                with_grad=True):
+                with_grad=True, defer_losses=False):
+        """defer_losses: the loss scalars are reduced inside the first backward launch instead of a
+        launch of their own (self.losses is then valid after backward(); needs with_grad and Yq_full)."""
         N, way, shot, K, C, h, w, H, W = self.dims
         P = [params[k] for k in PARAM_ORDER]
+        self._deferred = bool(defer_losses and with_grad and Yq_full is not None)
+        self._have_focal = Yq is not None
+        mode = _lib.GRAD_DEFER_LOSSES if self._deferred else (1 if with_grad else 0)
         call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask, weight_mask,
-             N, way, shot, K, C, h, w, H, W, 1 if with_grad else 0, self.logits_full, self.logits_binary,
+             N, way, shot, K, C, h, w, H, W, mode, self.logits_full, self.logits_binary,
              self.losses, self.ws, self.ws_bytes, self._probe)
 
     def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None):
@@ -69,4 +76,5 @@ class HeadStepEngine:
              params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
              N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
              g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
-             g["map.linear.bias"], self.ws, self.ws_bytes, self._probe)
+             g["map.linear.bias"], self.losses if self._deferred else None, 1 if self._have_focal else 0,
+             self.ws, self.ws_bytes, self._probe)

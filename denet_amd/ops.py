@@ -48,6 +48,17 @@ def masked_sum(Fs: torch.Tensor, mask: torch.Tensor):
     return S
 
 
+def masked_pool(Fs: torch.Tensor, Ys: torch.Tensor):
+    """K0 + K1 in one launch: Fs [B,C,h,w], Ys [B,H,W] int64 -> (mask [B,P], cnt [B], S [B,C])."""
+    Fs = Fs.contiguous()
+    Ys = _as_i64(Ys).contiguous()
+    B, C, h, w = Fs.shape
+    H, W = Ys.shape[-2:]
+    mask, cnt, S = _f32(B, h * w, device=Fs.device), _f32(B, device=Fs.device), _f32(B, C, device=Fs.device)
+    call("denet_masked_pool_fwd", Fs, feat_code(Fs), Ys, B, C, H, W, h, w, mask, cnt, S)
+    return mask, cnt, S
+
+
 def masked_sum_bwd(mask, coef, shape, dtype):
     B, C, h, w = shape
     dFs = torch.empty(B, C, h, w, dtype=dtype, device=mask.device)
@@ -247,9 +258,7 @@ class EstimatorFunction(torch.autograd.Function):
         N, way, shot, C, h, w = Fs.shape
         K = weight.shape[0]
         B, P = N * way * shot, h * w
-        Fs_m = Fs.contiguous().reshape(B, C, h, w)
-        mask, cnt = mask_resize(Ys.reshape(B, *Ys.shape[-2:]), h, w)
-        S = masked_sum(Fs_m, mask)
+        mask, cnt, S = masked_pool(Fs.contiguous().reshape(B, C, h, w), Ys.reshape(B, *Ys.shape[-2:]))
         params = tuple(t.contiguous() for t in (W1, b1, W2, b2, Wl, bl, weight))
         labels = _as_i64(labels).contiguous()
         Wn, saved = proto_extend(S, cnt, params, labels, N, way, shot, K, P, gate_mask, weight_mask)
@@ -294,8 +303,7 @@ class ExtendFunction(torch.autograd.Function):
         N, way, shot, C, h, w = Fs.shape
         K = weight.shape[0]
         B, P = N * way * shot, h * w
-        mask, cnt = mask_resize(Ys.reshape(B, *Ys.shape[-2:]), h, w)
-        S = masked_sum(Fs.contiguous().reshape(B, C, h, w), mask)
+        mask, cnt, S = masked_pool(Fs.contiguous().reshape(B, C, h, w), Ys.reshape(B, *Ys.shape[-2:]))
         params = tuple(t.contiguous() for t in (W1, b1, W2, b2, Wl, bl, weight))
         labels = _as_i64(labels).contiguous()
         proto = _f32(N * way, C, device=Fs.device)
@@ -422,6 +430,7 @@ class HeadStepFunction(torch.autograd.Function):
              gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
              ws, nbytes, None)
         ctx.dims = (N, way, shot, K, C, h, w, H, W)
+        ctx.have_focal = Yq is not None
         ctx.ws = ws
         ctx.fs_shape = Fs.shape
         ctx.save_for_backward(Fq, labels, params[1], params[3], params[5],
@@ -450,6 +459,6 @@ class HeadStepFunction(torch.autograd.Function):
         db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
         g = g_k.contiguous().float().reshape(1)
         call("denet_head_step_bwd", Fq, feat_code(Fq), labels, W1, W2, Wl, gate_mask, weight_mask, g,
-             N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, ctx.ws,
-             ctx.ws.numel(), None)
+             N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, None,
+             1 if ctx.have_focal else 0, ctx.ws, ctx.ws.numel(), None)
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7

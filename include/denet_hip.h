@@ -55,6 +55,11 @@ int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_t W, int64_
                       float* mask /*[B,h*w]*/, float* cnt /*[B]*/, void* stream);
 int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float* mask, int64_t B, int64_t C,
                          int64_t P, float* S /*[B,C]*/, void* stream);
+/* K0 + K1 in one launch: the mask is gathered from Ys [B,H,W] inside the pooling kernel, and
+ * mask [B,h*w] / cnt [B] are written out for the backward pass. */
+int denet_masked_pool_fwd(const void* Fs, int feat_dtype, const int64_t* Ys, int64_t B, int64_t C,
+                          int64_t H, int64_t W, int64_t h, int64_t w, float* mask, float* cnt, float* S,
+                          void* stream);
 /* Backward of the above (autograd of model/common.py:192,239,243,245):
  *   dFs[b,c,p] = mask[b,p] * coef[b,c]     (rank-1; Fs itself is not re-read) */
 int denet_masked_sum_bwd(const float* mask, const float* coef /*[B,C]*/, int64_t B, int64_t C,
@@ -206,7 +211,10 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
  * Everything DENetTrainer.step does between the feature producer and
  * optimizer.step() (trainer/trainers.py:951-975; wrappers trainer/utils.py:
  * 251-303): K0..K5 forward (+ the loss gradient slabs when with_grad), then
- * K3b, K2b, K1b.  ws: denet_head_step_workspace(...) bytes, 256-B aligned,
+ * K3b, K2b, K1b, as three launches whose independent halves run side by side (B1: dWn slabs;
+ * B2: K2b chain || dFq; B3: parameter gradients || dFs).  with_grad = DENET_GRAD_DEFER_LOSSES
+ * moves the reduction of the loss partials into B1 (losses[] is then valid after the backward
+ * call, and the forward needs Yq_full).  ws: denet_head_step_workspace(...) bytes, 256-B aligned,
  * shared by the two calls of one step.  Yq / Yq_full may be NULL (test mode:
  * no loss, trainer/trainers.py:958).  losses = {loss_k, loss_p} on device.
  * grad_loss_k: device scalar d(objective)/d(loss_k), NULL = 1.  Only loss_k is
@@ -215,18 +223,17 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
  * probe (HOST pointer, may be NULL): brackets ONE kernel of the step with the
  * caller's HIP events, recorded on `stream`, so a harness can time that kernel
  * inside its own timed region (bench.py's roofline line). */
-#define DENET_K_MASK_RESIZE      1
-#define DENET_K_MASKED_SUM_FWD   2
+#define DENET_GRAD_DEFER_LOSSES  2   /* with_grad value: losses[] is written by denet_head_step_bwd */
+#define DENET_K_MASK_RESIZE      1   /* (stand-alone K0 only; the fused step gathers the mask inside K1) */
+#define DENET_K_MASKED_SUM_FWD   2   /* K0+K1: mask gather + masked channel sums                 */
 #define DENET_K_PROTO_EXTEND_FWD 3
 #define DENET_K_CLASSIFY_FWD     4
-#define DENET_K_WCE_FWD          5
-#define DENET_K_FOCAL_FWD        6
+#define DENET_K_WCE_FWD          5   /* K4 (+K5 in the same launch when both label maps are given) */
+#define DENET_K_FOCAL_FWD        6   /* K5 alone (no Yq_full)                                      */
 #define DENET_K_LOSS_FINALIZE    7
-#define DENET_K_CLASSIFY_BWD     8
-#define DENET_K_PE_BWD_CHAIN     9   /* K2b: per-group chain of transposed mat-vecs            */
-#define DENET_K_MASKED_SUM_BWD   10
-#define DENET_K_PE_BWD_REDUCE    11  /* K2b: sum of the classifier's per-tile dWn slabs         */
-#define DENET_K_PE_BWD_PARAMS    12  /* K2b: parameter gradients                                */
+#define DENET_K_CLASSIFY_BWD     8   /* B1: dWn slabs (+ deferred loss reduction)                  */
+#define DENET_K_PE_BWD_CHAIN     9   /* B2: K2b chain of transposed mat-vecs || dFq             */
+#define DENET_K_MASKED_SUM_BWD   10  /* B3: K2b parameter gradients || dFs = mask*coef          */
 typedef struct denet_probe {
     int32_t which;      /* DENET_K_* */
     int32_t reserved;
@@ -250,7 +257,9 @@ int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
                         const float* gate_mask, const float* weight_mask, const float* grad_loss_k,
                         int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                         int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
-                        float* db2, float* dWl, float* dbl, void* ws, int64_t ws_bytes,
+                        float* db2, float* dWl, float* dbl,
+                        float* losses /* [2]; NULL unless the forward ran with DENET_GRAD_DEFER_LOSSES */,
+                        int have_focal /* the forward was given Yq */, void* ws, int64_t ws_bytes,
                         const denet_probe_t* probe, void* stream);
 
 #ifdef __cplusplus

@@ -181,3 +181,35 @@ def test_fused_confmat_planted_margin(dev, golden_dir):
     mat = torch.zeros(K, K, dtype=torch.int64, device=dev)
     ops.confmat_update(mat, ep["Yq_full"].to(dev), torch.from_numpy(z["out:logits_full"]).to(dev))
     assert np.array_equal(mat.cpu().numpy(), z["out:confmat"])
+
+
+@pytest.mark.parametrize("name", ["eval_1way_5shot", "eval_2way_3shot"])
+def test_engine_deferred_losses_match_eager(name, dev):
+    """The allocation-free engine with the loss reduction folded into the first backward launch
+    (what bench.py times) gives the same bits as the autograd path, and is stable across steps."""
+    from denet_amd import ops
+    from denet_amd.engine import HeadStepEngine, PARAM_ORDER
+    z, d, ep, params, gm, wm = load_case(name)
+    N, way, shot, K, c, h, w, H, W = (d[k] for k in ("N", "way", "shot", "K", "c", "h", "w", "H", "W"))
+    P_ = {k: params[k].to(dev).contiguous() for k in PARAM_ORDER}
+    Fq, Fs = ep["Fq"].float().to(dev), ep["Fs"].float().to(dev)
+    lab = ep["label"].reshape(N, way).to(dev)
+    Ys, Yq, Yf, wgt = ep["Ys"].to(dev), ep["Yq"].to(dev), ep["Yq_full"].to(dev), ep["wgt"].to(dev).contiguous()
+    eng = HeadStepEngine(N, way, shot, K, c, h, w, H, W, dev)
+    snaps = []
+    for defer in (False, True, True):
+        eng.losses.zero_()
+        eng.forward(Fq, Fs, Ys, lab, Yq, Yf, wgt, P_, with_grad=True, defer_losses=defer)
+        eng.backward(Fq, lab, P_)
+        torch.cuda.synchronize()
+        snaps.append([eng.losses.clone(), eng.dFq.clone(), eng.dFs.clone(), eng.grad_bucket.clone(),
+                      eng.logits_full.clone(), eng.logits_binary.clone()])
+    for other in snaps[1:]:
+        for a, b in zip(snaps[0], other):
+            assert torch.equal(a, b)
+    assert rel_err(snaps[0][0][0].cpu(), z["out:loss_k"]) < 1e-4
+    assert rel_err(snaps[0][0][1].cpu(), z["out:loss_p"]) < 1e-4
+    assert rel_err(snaps[0][1].cpu(), z["out:dFq"]) < TOL
+    assert rel_err(snaps[0][2].reshape(ep["Fs"].shape).cpu(), z["out:dFs"]) < TOL
+    for k in PARAM_ORDER:
+        assert rel_err(eng.grads[k].cpu(), z["grad:" + k]) < TOL, k
