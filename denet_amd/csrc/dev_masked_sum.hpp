@@ -36,6 +36,63 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     const int c0 = cblk * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* mrow = mask + (int64_t)b * P;
+    constexpr int V = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
+    constexpr int NR = 2;                                 // rows of a wave in flight together (more costs occupancy)
+    const bool short_rows = (P / V) <= NV * 64;           // P <= 2048 fp32 / 4096 bf16 elements
+
+    // ---- fast path, part 1: EVERY feature load of the wave's first NR rows is issued before anything
+    // else -- they do not depend on the mask -- all unconditional (clamped index, value selected later:
+    // a load inside a branch makes the compiler drain vmcnt at the join), so the block pays ONE memory
+    // round trip for the mask gather and the feature rows together.
+    vec_t v[NR][NV];
+    float hv[NR], tv[NR];
+    int heads[NR], nvecs[NR];
+    auto issue = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + 4 * q, c = c0 + r;
+            const bool live = (r < rows_per_block) && (c < C);
+            const T* row = Fs + ((int64_t)b * C + (live ? c : c0)) * P;
+            const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
+            int head = mis ? V - mis : 0;
+            if (head > P) head = P;
+            const int nvec = (P - head) / V;
+            heads[q] = head; nvecs[q] = nvec;
+            const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
+            hv[q] = FeatIO<T>::load(row + min(lane, P - 1));
+            tv[q] = FeatIO<T>::load(row + min(head + nvec * V + lane, P - 1));
+#pragma unroll
+            for (int u = 0; u < NV; ++u) v[q][u] = rv[min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0)];
+        }
+    };
+    auto consume = [&](int r0) {
+        float accs[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int head = heads[q], nvec = nvecs[q], t0 = head + nvec * V;
+            float acc = (lane < head) ? hv[q] * sm[min(lane, P - 1)] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = lane + 64 * u;
+                const float d = Vec16<T>::dot(v[q][u], sm + head + min(i, nvec > 0 ? nvec - 1 : 0) * V);
+                acc += (i < nvec) ? d : 0.f;
+            }
+            acc += (t0 + lane < P) ? tv[q] * sm[min(t0 + lane, P - 1)] : 0.f;
+            accs[q] = wave_sum(acc);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + 4 * q;
+            if (r < rows_per_block && c0 + r < C && lane == 0) S[(int64_t)b * C + c0 + r] = accs[q];
+        }
+    };
+    if (short_rows) issue(wave);
+
+    // ---- the mask: gathered here from the int64 label map (K0 fused: nearest resize,
+    // model/common.py:189-190; the block with cblk == 0 also writes mask[b,:] and cnt[b] for the backward
+    // pass), or read from `mask`.
     if (Ys != nullptr) {
         const float sy = nearest_scale(H, h), sx = nearest_scale(W, w);
         const int64_t* src = Ys + (int64_t)b * H * W;
@@ -57,61 +114,20 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
         }
     } else {
-        // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
-        // latency once per iteration)
 #pragma unroll 8
         for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
     }
     __syncthreads();
 
-    constexpr int V = Vec16<T>::N;
-    typedef typename Vec16<T>::type vec_t;
-    constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
-    if ((P / V) <= NV * 64) {
-        // Short rows (P <= 2048 fp32 / 4096 bf16 elements): every load of TWO rows is issued before the
-        // first use, all of them unconditional (clamped index, value selected afterwards), so a wave
-        // pays one memory round trip per pair of rows instead of three per row.
-        for (int r = wave; r < rows_per_block; r += 8) {
-            float accs[2];
-            vec_t v[2][NV];
-            float hv[2], tv[2];
-            int heads[2], nvecs[2];
-            bool live[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int c = c0 + r + 4 * q;
-                live[q] = (r + 4 * q < rows_per_block) && (c < C);
-                const T* row = Fs + ((int64_t)b * C + (live[q] ? c : c0)) * P;
-                const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
-                int head = mis ? V - mis : 0;
-                if (head > P) head = P;
-                const int nvec = (P - head) / V;
-                heads[q] = head; nvecs[q] = nvec;
-                const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
-                hv[q] = FeatIO<T>::load(row + min(lane, P - 1));
-                tv[q] = FeatIO<T>::load(row + min(head + nvec * V + lane, P - 1));
-#pragma unroll
-                for (int u = 0; u < NV; ++u) v[q][u] = rv[min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0)];
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int head = heads[q], nvec = nvecs[q], t0 = head + nvec * V;
-                float acc = (lane < head) ? hv[q] * sm[min(lane, P - 1)] : 0.f;
-#pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const int i = lane + 64 * u;
-                    const float d = Vec16<T>::dot(v[q][u], sm + head + min(i, nvec > 0 ? nvec - 1 : 0) * V);
-                    acc += (i < nvec) ? d : 0.f;
-                }
-                acc += (t0 + lane < P) ? tv[q] * sm[min(t0 + lane, P - 1)] : 0.f;
-                accs[q] = wave_sum(acc);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (live[q] && lane == 0) S[(int64_t)b * C + c0 + r + 4 * q] = accs[q];
+    if (short_rows) {
+        consume(wave);
+        for (int r = wave + 4 * NR; r < rows_per_block; r += 4 * NR) {
+            issue(r);
+            consume(r);
         }
         return;
     }
+    // ---- long rows: stream each row with a rolling loop
     for (int r = wave; r < rows_per_block; r += 4) {
         const int c = c0 + r;
         if (c >= C) break;
@@ -119,18 +135,18 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
         int head = mis ? V - mis : 0;
         if (head > P) head = P;
-        const float hv = FeatIO<T>::load(row + min(lane, P - 1));
-        float acc = (lane < head) ? hv * sm[min(lane, P - 1)] : 0.f;
+        const float hv1 = FeatIO<T>::load(row + min(lane, P - 1));
+        float acc = (lane < head) ? hv1 * sm[min(lane, P - 1)] : 0.f;
         const int nvec = (P - head) / V;
         const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
         const int t0 = head + nvec * V;
-        const float tv = FeatIO<T>::load(row + min(t0 + lane, P - 1));
+        const float tv1 = FeatIO<T>::load(row + min(t0 + lane, P - 1));
 #pragma unroll 4
         for (int i = lane; i < nvec; i += 64) {
-            vec_t v = rv[i];
-            acc += Vec16<T>::dot(v, sm + head + i * V);
+            vec_t vv = rv[i];
+            acc += Vec16<T>::dot(vv, sm + head + i * V);
         }
-        acc += (t0 + lane < P) ? tv * sm[min(t0 + lane, P - 1)] : 0.f;
+        acc += (t0 + lane < P) ? tv1 * sm[min(t0 + lane, P - 1)] : 0.f;
         acc = wave_sum(acc);
         if (lane == 0) S[(int64_t)b * C + c] = acc;
     }

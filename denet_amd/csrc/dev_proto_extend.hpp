@@ -14,14 +14,30 @@
 // ---------------------------------------------------------------------------
 #define CH_THREADS 512
 
-template <int CH>
+// NV = number of live columns of vin (images of the group): only those are read and multiplied.
+// The first mat-vec of the chain has ONE (dproto is the same for every shot), the others `shot`.
+template <int CH, int NV>
 __device__ __forceinline__ void cols_chunk(const float (&wr)[CH], const float* vin /*[C][8]*/, int o0, float (&acc)[8]) {
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(vin + (o0 + t) * 8 + 4);
-        acc[0] += wr[t] * v0[0]; acc[1] += wr[t] * v0[1]; acc[2] += wr[t] * v0[2]; acc[3] += wr[t] * v0[3];
-        acc[4] += wr[t] * v1[0]; acc[5] += wr[t] * v1[1]; acc[6] += wr[t] * v1[2]; acc[7] += wr[t] * v1[3];
+        const float* vp = vin + (o0 + t) * 8;
+        if constexpr (NV == 1) {
+            acc[0] += wr[t] * vp[0];
+        } else if constexpr (NV <= 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
+#pragma unroll
+            for (int s = 0; s < NV; ++s) acc[s] += wr[t] * v0[s];
+        } else {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
+            acc[0] += wr[t] * v0[0]; acc[1] += wr[t] * v0[1]; acc[2] += wr[t] * v0[2]; acc[3] += wr[t] * v0[3];
+            if constexpr (NV == 5) {
+                acc[4] += wr[t] * vp[4];
+            } else {
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+                for (int s = 4; s < NV; ++s) acc[s] += wr[t] * v1[s - 4];
+            }
+        }
     }
 }
 
@@ -43,8 +59,8 @@ struct PeChainArgs {
 #define PE_CHAIN_LDS(C) ((size_t)((C) * 8 + CH_THREADS * 8 + (C) + 3 * (C) * 8) * 4)
 
 // Body for group `grp` = (episode, way); 512 threads; sm: PE_CHAIN_LDS(C) bytes.
-template <int C, int CH>
-__device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a, int grp, float* sm) {
+template <int C, int CH, int NS>
+__device__ __forceinline__ void proto_extend_bwd_chain_body_ns(const PeChainArgs& a, int grp, float* sm) {
     const float* __restrict__ dWn_part = a.dWn_part;
     const float* __restrict__ S = a.S;
     const float* __restrict__ cnt = a.cnt;
@@ -83,6 +99,7 @@ __device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a
 #pragma unroll
         for (int q = 0; q < CH; ++q) dst[q] = p[(int64_t)q * C];
     };
+    STAMP(0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (t < T) issue(t, ring[t]);
@@ -133,6 +150,7 @@ __device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a
     }
     __syncthreads();
 
+    STAMP(1);
     float acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = 0.f;
@@ -140,8 +158,10 @@ __device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a
     for (int t = 0; t < T; ++t) {
         if (t + 3 < T) issue(t + 3, ring[(t + 3) & 3]);
         const int mv = t / NCH, ch = t % NCH;
-        cols_chunk<CH>(ring[t & 3], vin, sp * R + ch * CH, acc);
+        if (mv == 0) cols_chunk<CH, 1>(ring[t & 3], vin, sp * R + ch * CH, acc);
+        else cols_chunk<CH, NS>(ring[t & 3], vin, sp * R + ch * CH, acc);
         if (ch == NCH - 1) {
+            if (mv == 0) { STAMP(2); } else if (mv == 1) { STAMP(4); } else { STAMP(6); }
 #pragma unroll
             for (int s = 0; s < 8; ++s) { red[(sp * 8 + s) * C + ci] = acc[s]; acc[s] = 0.f; }
             __syncthreads();
@@ -175,8 +195,18 @@ __device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a
                 }
             }
             __syncthreads();
+            if (mv == 0) { STAMP(3); } else if (mv == 1) { STAMP(5); } else { STAMP(7); }
         }
     }
+}
+
+// dispatch on the number of images per group (shot <= 8)
+template <int C, int CH>
+__device__ __forceinline__ void proto_extend_bwd_chain_body(const PeChainArgs& a, int grp, float* sm) {
+    if (a.shot == 1) proto_extend_bwd_chain_body_ns<C, CH, 1>(a, grp, sm);
+    else if (a.shot <= 3) proto_extend_bwd_chain_body_ns<C, CH, 3>(a, grp, sm);
+    else if (a.shot <= 5) proto_extend_bwd_chain_body_ns<C, CH, 5>(a, grp, sm);
+    else proto_extend_bwd_chain_body_ns<C, CH, 8>(a, grp, sm);
 }
 
 template <int C, int CH>
@@ -257,15 +287,18 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
 #pragma unroll 4
         for (int p = grp; p < pairs; p += 16) {
             const int n = p / n_part, q = p - n * n_part;
+            // all loads unconditional and independent of each other (labels, slab, mask): the novel
+            // rows are dropped by a select, not by a branch around the loads
+            f32x4 v = *reinterpret_cast<const f32x4*>(dWn_part + (((int64_t)n * n_part + q) * K + k) * C + col);
             bool novel = false;
             for (int jj = 0; jj < way; ++jj) novel = novel || (labels[(int64_t)n * way + jj] == k);
-            if (novel) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(dWn_part + (((int64_t)n * n_part + q) * K + k) * C + col);
             if (weight_mask) {
                 const f32x4 m = *reinterpret_cast<const f32x4*>(weight_mask + ((int64_t)n * K + k) * C + col);
                 v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
             }
-            t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3];
+            const float keep = novel ? 0.f : 1.f;
+            t[0] = fmaf(keep, v[0], t[0]); t[1] = fmaf(keep, v[1], t[1]);
+            t[2] = fmaf(keep, v[2], t[2]); t[3] = fmaf(keep, v[3], t[3]);
         }
         redw[tid] = t;
         __syncthreads();
@@ -286,23 +319,18 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
     const float vs = which == 0 ? 1.f / Pf : 1.f;
     float* dW = which == 0 ? dW1 : (which == 1 ? dW2 : dWl);
     float* db = which == 0 ? db1 : (which == 1 ? db2 : dbl);
+    // One output row per block (WG_ROWS == 1).  U[b, o0] is the same address for every lane, so the
+    // bias gradient db[o0] = sum_b U[b, o0] falls out of the same loads; 16 images in flight at a time.
     for (int i = tid; i < C; i += 256) {
-        float acc[WG_ROWS];
-#pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll 8
+        float acc = 0.f, sdb = 0.f;
+#pragma unroll 16
         for (int b = 0; b < B; ++b) {
-            const float v = V[(int64_t)b * C + i];
-#pragma unroll
-            for (int r = 0; r < WG_ROWS; ++r) acc[r] += U[(int64_t)b * C + o0 + r] * v;
+            const float u = U[(int64_t)b * C + o0];
+            acc = fmaf(u, V[(int64_t)b * C + i], acc);
+            sdb += u;
         }
-#pragma unroll
-        for (int r = 0; r < WG_ROWS; ++r) dW[(int64_t)(o0 + r) * C + i] = acc[r] * vs;
-    }
-    if (tid < WG_ROWS) {
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += U[(int64_t)b * C + o0 + tid];
-        db[o0 + tid] = t;
+        dW[(int64_t)o0 * C + i] = acc * vs;
+        if (i == 0) db[o0] = sdb;
     }
 }
 

@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, con
                                                            const float* __restrict__ coef, T* __restrict__ dFs, int C,
                                                            int P, int rpb, int ncb, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bx = blockIdx.x;
-    if (bx < 4 * gx) {
-        proto_extend_bwd_params_body(pa, bx / gx, bx % gx, sm);
+    const int bx = blockIdx.x, nms = gridDim.x - 4 * gx;
+    if (bx < nms) {
+        masked_sum_bwd_body<T>(mask, coef, dFs, C, P, rpb, bx / ncb, bx % ncb, sm);
     } else {
-        const int r = bx - 4 * gx;
-        masked_sum_bwd_body<T>(mask, coef, dFs, C, P, rpb, r / ncb, r % ncb, sm);
+        const int r = bx - nms;
+        proto_extend_bwd_params_body(pa, r / gx, r % gx, sm);
     }
 }
 
