@@ -70,6 +70,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// XCD-aware block mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear block id, and each
+// XCD has its own L2.  v = xcd_swizzle(id, total) renumbers the blocks so that CONSECUTIVE v land on the
+// SAME XCD (v in [x*total/8, (x+1)*total/8) runs on XCD x): blocks that share read-only data (the 16
+// channel blocks of one support image share its mask gather) then hit in one L2 instead of fetching
+// the data once per XCD.  Speed only: any placement is correct.
+__device__ __forceinline__ int xcd_swizzle(int id, int total) {
+    const int per = total >> 3;
+    if (id >= (per << 3)) return id;             // remainder blocks keep their id
+    return (id & 7) * per + (id >> 3);
+}
+
 // bf16 <-> f32
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) {
     return __uint_as_float(((unsigned int)u) << 16);

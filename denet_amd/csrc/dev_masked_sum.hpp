@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
                                                             float* __restrict__ S, int C, int P,
                                                             int rows_per_block, int H, int W, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [P] (+ 4)
-    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, blockIdx.y, blockIdx.x, sm);
+    // 1-D grid of ncb * B blocks; the ncb channel blocks of an image are placed on one XCD (shared gather)
+    const int ncb = (C + rows_per_block - 1) / rows_per_block;
+    const int v = xcd_swizzle(blockIdx.x, gridDim.x);
+    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm);
 }
 
 // ---------------------------------------------------------------------------

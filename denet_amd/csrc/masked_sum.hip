@@ -60,7 +60,7 @@ extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float*
     if (!fits_int(B) || !fits_int(C) || !fits_int(P)) return DENET_E_BADARG;
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
-    dim3 grid((unsigned)((C + rpb - 1) / rpb), (unsigned)B);
+    dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
     size_t lds = (size_t)P * 4 + 32;
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
@@ -108,7 +108,7 @@ extern "C" int denet_masked_pool_fwd(const void* Fs, int feat_dtype, const int64
     const int64_t P = h * w;
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
-    dim3 grid((unsigned)((C + rpb - 1) / rpb), (unsigned)B);
+    dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
     size_t lds = (size_t)P * 4 + 32;
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,

@@ -11,7 +11,7 @@ Writes profiles/<tag>_kernel_stats.csv (copy of the stats table), profiles/<tag>
 PMC passes, profiles/pmc_traffic.json: per kernel, HBM bytes per launch =
 f * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (FETCH_SIZE/WRITE_SIZE are in KiB).  f = 2 for kernels whose streamed
 loads are 16 B per lane (on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read:
-MI355X_MICROARCH.md §HBM; calibrated here on masked_sum_fwd, whose 68.9 MB stream reads 34.7 MiB raw) and f = 1
+MI355X_MICROARCH.md §HBM; calibrated here on masked_pool_fwd (K0+K1), whose 68.9 MB stream reads 34.7 MiB raw) and f = 1
 for kernels that stream with 8-B-per-lane loads (calibrated on wce_fwd: 7.1 MB of int64 labels + logits read
 7.4 MiB raw, which includes the halo columns).  Raw values are kept beside the corrected figure.
 """
@@ -26,7 +26,9 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-NAMES = [("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_sum_fwd"),
+NAMES = [("upsample_loss_pair_kernel", "loss_pair_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"),
+         ("head_bwd_mid_kernel", "bwd_chain_dfq"), ("head_bwd_tail_kernel", "bwd_params_dfs"),
+         ("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_pool_fwd"),
          ("proto_extend_fwd_kernel", "proto_extend_fwd"), ("classify_fwd_kernel", "classify_fwd"),
          ("upsample_loss_kernel<0, true>", "wce_fwd"), ("upsample_loss_kernel<0, false>", "wce_fwd_nograd"),
          ("upsample_loss_kernel<1, false>", "focal_fwd"), ("loss_finalize_kernel", "loss_finalize"),
@@ -37,8 +39,8 @@ NAMES = [("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "maske
 
 
 # read-side correction factor per kernel (see module docstring); anything else: 1, flagged uncalibrated
-READ_FACTOR = {"masked_sum_fwd": 2, "masked_sum_bwd": 2, "pe_bwd_reduce": 2, "proto_extend_fwd": 2,
-               "wce_fwd": 1, "focal_fwd": 1, "wce_fwd_nograd": 1, "mask_resize": 1}
+READ_FACTOR = {"masked_pool_fwd": 2, "masked_sum_bwd": 2, "pe_bwd_reduce": 2, "proto_extend_fwd": 2,
+               "wce_fwd": 1, "focal_fwd": 1, "wce_fwd_nograd": 1, "mask_resize": 1, "loss_pair_fwd": 1}
 
 
 def short(name):
