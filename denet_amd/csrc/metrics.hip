@@ -14,6 +14,11 @@ __device__ __forceinline__ bool argmax_better(float v, float best) {
 }
 
 // ---- API-level: preds already up-sampled [N,K,HW] ----------------------------
+// HBM-bound (K*HW*4 bytes per sample).  Each thread owns 4 consecutive pixels and walks the classes
+// with 16-byte loads (rows of different classes are only element-aligned: HW is odd for 321x321),
+// four classes in flight at a time; counts go to an LDS-privatised histogram, then to the int64 matrix.
+typedef float f32x4_mu __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(MT_THREADS) void confmat_kernel(const float* __restrict__ preds,
                                                             const int64_t* __restrict__ yt, int K, int64_t HW,
                                                             int chunk, unsigned long long* __restrict__ mat) {
@@ -25,16 +30,35 @@ __global__ __launch_bounds__(MT_THREADS) void confmat_kernel(const float* __rest
     const int64_t q1 = q0 + chunk < HW ? q0 + chunk : HW;
     const float* pn = preds + (int64_t)n * K * HW;
     const int64_t* tn = yt + (int64_t)n * HW;
-    for (int64_t q = q0 + threadIdx.x; q < q1; q += MT_THREADS) {
-        const int64_t t = tn[q];
-        if (t < 0 || t >= K) continue;
-        float best = pn[q];
-        int bi = 0;
-        for (int k = 1; k < K; ++k) {
-            const float v = pn[(int64_t)k * HW + q];
-            if (argmax_better(v, best)) { best = v; bi = k; }
+    for (int64_t q = q0 + 4 * threadIdx.x; q < q1; q += 4 * MT_THREADS) {
+        if (q + 4 <= HW) {
+            int64_t t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = tn[q + e];
+            f32x4_mu best = *reinterpret_cast<const f32x4_mu*>(pn + q);
+            int bi[4] = {0, 0, 0, 0};
+#pragma unroll 4
+            for (int k = 1; k < K; ++k) {
+                const f32x4_mu v = *reinterpret_cast<const f32x4_mu*>(pn + (int64_t)k * HW + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (argmax_better(v[e], best[e])) { best[e] = v[e]; bi[e] = k; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t[e] >= 0 && t[e] < K) atomicAdd(&hist[(int)t[e] * K + bi[e]], 1u);
+        } else {
+            for (int64_t qq = q; qq < HW; ++qq) {            // last (< 4) pixels of the sample
+                const int64_t t = tn[qq];
+                float best = pn[qq];
+                int bi = 0;
+                for (int k = 1; k < K; ++k) {
+                    const float v = pn[(int64_t)k * HW + qq];
+                    if (argmax_better(v, best)) { best = v; bi = k; }
+                }
+                if (t >= 0 && t < K) atomicAdd(&hist[(int)t * K + bi], 1u);
+            }
         }
-        atomicAdd(&hist[(int)t * K + bi], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K * K; i += MT_THREADS)
@@ -183,10 +207,10 @@ __global__ __launch_bounds__(MT_THREADS) void fused_metric_kernel(const float* _
 static inline bool pos(int64_t v) { return v > 0 && v < ((int64_t)1 << 30); }
 
 static int pick_chunk(int64_t HW, int64_t N, unsigned* gx) {
-    // ~1024 blocks in flight at most; each block at least 4096 pixels
-    int64_t per = (HW * N + 1023) / 1024;
-    if (per < 4096) per = 4096;
-    per = (per + 255) / 256 * 256;
+    // ~4096 blocks at most; each block at least 1024 pixels (4 per thread), in multiples of 1024
+    int64_t per = (HW * N + 4095) / 4096;
+    if (per < 1024) per = 1024;
+    per = (per + 1023) / 1024 * 1024;
     *gx = (unsigned)((HW + per - 1) / per);
     return (int)per;
 }

@@ -34,23 +34,44 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
 
 // Plain up-sampling, ATen's operation order without FMA contraction:
 //   out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+// Write-bound (H*W*4 bytes per channel image): one thread per 4 consecutive output columns of one row,
+// the row's vertical taps computed once per thread, 16-byte stores where the address allows.
+typedef float f32x4_su __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ x, int h, int w, int H,
                                                                int W, float* __restrict__ out) {
     const int nc = blockIdx.y;
     const float sy = bilinear_scale(h, H), sx = bilinear_scale(w, W);
     const float* src = x + (int64_t)nc * h * w;
     float* dst = out + (int64_t)nc * H * W;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < H * W; q += gridDim.x * 256) {
-        const int qy = q / W, qx = q - qy * W;
-        int y0, x0;
-        float fy, fx;
+    const int W4 = (W + 3) >> 2;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < H * W4; it += gridDim.x * 256) {
+        const int qy = it / W4, x4 = (it - qy * W4) * 4;
+        int y0;
+        float fy;
         bilinear_tap(qy, sy, h, y0, fy);
-        bilinear_tap(qx, sx, w, x0, fx);
-        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
-        const float h1 = fy, h0 = 1.f - fy, w1 = fx, w0 = 1.f - fx;
-        const float top = __fadd_rn(__fmul_rn(w0, src[y0 * w + x0]), __fmul_rn(w1, src[y0 * w + x1]));
-        const float bot = __fadd_rn(__fmul_rn(w0, src[y1 * w + x0]), __fmul_rn(w1, src[y1 * w + x1]));
-        dst[q] = __fadd_rn(__fmul_rn(h0, top), __fmul_rn(h1, bot));
+        const int y1 = y0 + (y0 < h - 1);
+        const float h1 = fy, h0 = 1.f - fy;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qx = min(x4 + e, W - 1);
+            int x0;
+            float fx;
+            bilinear_tap(qx, sx, w, x0, fx);
+            const int x1 = x0 + (x0 < w - 1);
+            const float w1 = fx, w0 = 1.f - fx;
+            const float top = __fadd_rn(__fmul_rn(w0, src[y0 * w + x0]), __fmul_rn(w1, src[y0 * w + x1]));
+            const float bot = __fadd_rn(__fmul_rn(w0, src[y1 * w + x0]), __fmul_rn(w1, src[y1 * w + x1]));
+            v[e] = __fadd_rn(__fmul_rn(h0, top), __fmul_rn(h1, bot));
+        }
+        float* o = dst + (int64_t)qy * W + x4;
+        if (x4 + 4 <= W) {
+            f32x4_su vv = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4_su*>(o) = vv;
+        } else {
+            for (int e = 0; x4 + e < W; ++e) o[e] = v[e];
+        }
     }
 }
 
@@ -226,8 +247,8 @@ extern "C" int denet_upsample_bilinear(const float* x, int64_t NC, int64_t h, in
     if (!x || !out) return DENET_E_BADARG;
     if (!pos(NC) || !pos(h) || !pos(w) || !pos(H) || !pos(W) || !pos(H * W)) return DENET_E_BADARG;
     if (NC > 65535) return DENET_E_UNSUPPORTED;
-    unsigned gx = (unsigned)((H * W + 255) / 256);
-    if (gx > 64) gx = 64;
+    unsigned gx = (unsigned)((H * ((W + 3) / 4) + 255) / 256);
+    if (gx > 128) gx = 128;
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(gx, (unsigned)NC), dim3(256), 0, (hipStream_t)stream, x,
                        (int)h, (int)w, (int)H, (int)W, out);
     DENET_CHECK_LAUNCH();
