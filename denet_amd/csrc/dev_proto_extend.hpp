@@ -244,9 +244,9 @@ struct PeParamsArgs {
     float Pf;
     float *dW1, *db1, *dW2, *db2, *dWl, *dbl, *dweight;
 };
-// blocks per role: roles 0..2 need C/WG_ROWS blocks, role 3 needs K * C/64
+// blocks per role: roles 0..2 need C/WG_ROWS blocks, role 3 needs K * C/16
 __host__ __device__ __forceinline__ int pe_params_gx(int K, int C) {
-    const int a = C / WG_ROWS, b = K * (C >> 6);
+    const int a = C / WG_ROWS, b = K * (C >> 4);
     return a > b ? a : b;
 }
 
@@ -272,20 +272,20 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
     float* __restrict__ dweight = a.dweight;
     const int tid = threadIdx.x;
     if (which == 3) {
-        // dweight[k, 64-column chunk] = sum over (n, tile) of the partial slabs, novel rows and dropped
-        // entries excluded.  Block = (k, chunk); the 256 threads are 16 float4 columns x 16 groups that
-        // split the (n, tile) pairs, so every thread has all of its loads in flight at once; the groups
-        // are then summed through LDS in a fixed order.
+        // dweight[k, 16-column chunk] = sum over (n, tile) of the partial slabs, novel rows and dropped
+        // entries excluded.  Block = (k, chunk): K * C/16 blocks keep every CU streaming at large batches;
+        // the 256 threads are 4 float4 columns x 64 groups that split the (n, tile) pairs, so every
+        // thread has its loads in flight together; the groups are then summed through LDS in a fixed order.
         f32x4* redw = reinterpret_cast<f32x4*>(smem);
-        const int nchunk = C >> 6;
+        const int nchunk = C >> 4;
         const int k = bx / nchunk, chunk = bx - k * nchunk;
         if (k >= K) return;
-        const int c4 = tid & 15, grp = tid >> 4;
-        const int col = chunk * 64 + c4 * 4;
+        const int c4 = tid & 3, grp = tid >> 2;
+        const int col = chunk * 16 + c4 * 4;
         const int pairs = N * n_part;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int p = grp; p < pairs; p += 16) {
+#pragma unroll 8
+        for (int p = grp; p < pairs; p += 64) {
             const int n = p / n_part, q = p - n * n_part;
             // all loads unconditional and independent of each other (labels, slab, mask): the novel
             // rows are dropped by a select, not by a branch around the loads
@@ -302,13 +302,13 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
         }
         redw[tid] = t;
         __syncthreads();
-        if (tid < 16) {
+        if (tid < 4) {
             f32x4 r = redw[tid];
-            for (int g2 = 1; g2 < 16; ++g2) {
-                const f32x4 v = redw[g2 * 16 + tid];
+            for (int g2 = 1; g2 < 64; ++g2) {
+                const f32x4 v = redw[g2 * 4 + tid];
                 r[0] += v[0]; r[1] += v[1]; r[2] += v[2]; r[3] += v[3];
             }
-            *reinterpret_cast<f32x4*>(dweight + (int64_t)k * C + chunk * 64 + tid * 4) = r;
+            *reinterpret_cast<f32x4*>(dweight + (int64_t)k * C + chunk * 16 + tid * 4) = r;
         }
         return;
     }

@@ -30,3 +30,21 @@ def get_binary_logits(logits_full: torch.Tensor, label: torch.Tensor, base: bool
     reference never back-propagates through the binary logits (trainer/trainers.py:972-974)."""
     N = logits_full.shape[0]
     return ops.binary_logits(logits_full.detach(), label.reshape(N, 1), way=1, base=base)
+
+
+def process_nway(Yq_pre: torch.Tensor, way: int):
+    """Fuse the 2*way logits of a class-agnostic model into per-way binary scores
+    (trainer/utils.py:128-154): (N, 2*way, h, w) -> (N, way, 2, h, w).  Channel 2i is way i's
+    background, 2i+1 its foreground; the shared background is the max over the way backgrounds,
+    and way i's binary pair is get_binary_logits([bg, fg_0..fg_{way-1}], label = i + 1).
+
+    Parity note: trainer/utils.py cannot be imported in the build container (it pulls in
+    torchvision through model.head), so this function is restated from the source text and checked
+    against a plain-PyTorch restatement of the same lines (tests/test_gpu_api.py): parity unpinned."""
+    N = Yq_pre.shape[0]
+    x = Yq_pre.detach().float()
+    background = x[:, 0::2].max(dim=1, keepdim=True)[0]
+    scores = torch.cat([background, x[:, 1::2]], dim=1).contiguous()          # (N, way + 1, h, w)
+    labels = torch.arange(1, way + 1, device=x.device, dtype=torch.int64).repeat(N, 1)   # (N, way)
+    out = ops.binary_logits(scores, labels, way=way, base=True)                # (N*way, 2, h, w)
+    return out.reshape(N, way, 2, *x.shape[-2:])

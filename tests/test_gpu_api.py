@@ -217,3 +217,18 @@ def test_trainer_train_val_test_roundtrip(dev, tmp_path):
     assert 0.0 <= mb <= 1.0 and 0.0 <= mf <= 1.0
     with pytest.raises(ValueError):
         DENetTrainer(cfg, tcfg)
+
+
+def test_process_nway_matches_restatement(dev):
+    """trainer/utils.py:128-154 (parity unpinned: the reference module cannot be imported here)."""
+    from denet_amd.operations import process_nway
+    g = torch.Generator().manual_seed(5)
+    way, N = 3, 4
+    x = torch.randn(N, 2 * way, 7, 9, generator=g)
+    got = process_nway(x.to(dev), way).cpu()
+    bg = x[:, 0::2].max(1, keepdim=True)[0]
+    scores = torch.cat([bg, x[:, 1::2]], 1)
+    for i in range(way):
+        keep = [k for k in range(way + 1) if k != i + 1]
+        ref = torch.stack([scores[:, keep].max(1)[0], scores[:, i + 1]], 1)
+        assert torch.equal(got[:, i], ref)
