@@ -183,3 +183,44 @@ def test_edge_cases(dev):
     mat = torch.zeros(3, 3, dtype=torch.int64, device=dev)
     ops.confmat_update(mat, yt.to(dev), pr.to(dev))
     assert mat.cpu().tolist() == [[0, 0, 1], [0, 0, 1], [0, 0, 1]]
+
+
+def test_limits_and_duplicate_labels(dev):
+    """The documented limits (K = 128, shot = 8) and the reference's overwrite order when two ways of an
+    episode carry the same label (model/common.py:327-334: the later way wins), forward and backward."""
+    from denet_amd.synthetic import EpisodeShape, make_episodes
+    from oracle import denet_oracle as O
+    s = EpisodeShape("limits", N=2, way=3, shot=8, K=128, c=64, h=6, w=7, H=41, W=50, config_index=11)
+    ep = make_episodes(s, ignore_rows=1)
+    ep["label"][0] = torch.tensor([5, 9, 5])              # ways 0 and 2 collide: way 2's prototype is kept
+    ep["label"][1] = torch.tensor([127, 1, 64])
+    _, state, out = _run_step(s, dev, ep=ep)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["logits_binary"].cpu(), ref["logits_binary"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(out["loss_p"].cpu(), ref["loss_p"]) < 1e-4
+    assert rel_err(out["Fq"].grad.cpu(), ref["dFq"]) < 1e-3
+    assert rel_err(out["Fs"].grad.cpu(), ref["dFs"]) < 1e-3
+    # the losing way (episode 0, way 0) gets no gradient at all, like the overwritten row in the reference
+    assert float(out["Fs"].grad[0, 0].abs().max()) == 0.0 and float(ref["dFs"][0, 0].abs().max()) == 0.0
+    for k, t in zip(ORDER, out["P"]):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
+
+
+def test_unsupported_shapes_fail_loudly(dev):
+    """No fallback path: shapes outside the kernels' limits raise instead of computing something else."""
+    from denet_amd import _lib, ops
+    from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state
+    for kw in (dict(c=128), dict(shot=9), dict(K=129)):
+        s = EpisodeShape(**{**dict(name="bad", N=1, way=1, shot=1, K=5, c=64, h=5, w=5, H=17, W=17, config_index=12),
+                            **kw})
+        ep = make_episodes(s, ignore_rows=1)
+        state = make_estimator_state(s.K, s.c)
+        P = [state[k].to(dev) for k in ORDER]
+        with pytest.raises(_lib.DenetHipError):
+            ops.HeadStepFunction.apply(ep["Fq"].to(dev), ep["Fs"].to(dev), *P, ep["Ys"].to(dev),
+                                       ep["label"].reshape(s.N, s.way).to(dev), ep["Yq"].to(dev),
+                                       ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+    with pytest.raises(_lib.DenetHipError):
+        ops.masked_sum(torch.zeros(1, 64, 4, 4, dtype=torch.float16, device=dev), torch.zeros(1, 16, device=dev))
