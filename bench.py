@@ -44,15 +44,21 @@ def kernel_bytes(s: EpisodeShape, sF: int):
     N, way, shot, K, C = s.N, s.way, s.shot, s.K, s.c
     B, P, Q, NB = N * way * shot, s.h * s.w, s.H * s.W, N * way
     n_part = (P + 63) // 64
+    nsl, G = C // 16, N * way
     return {
-        "masked_pool_fwd": B * C * P * sF + B * P * 8 + B * P * 4 + B * C * 4,
-        "proto_extend_fwd": 3 * C * C * 4 + K * C * 4 + N * K * C * 4 + 4 * B * C * 4,
-        "classify_fwd": N * C * P * sF + N * K * C * 4 + N * K * P * 4 + NB * 2 * P * 4,
+        # Fs stream + mask gather + S, W1 slices (each element of W1 once per image) + layer-1 partials
+        "masked_pool_fwd": B * C * P * sF + B * P * 8 + B * P * 4 + B * C * 4 + B * C * C * 4 + B * nsl * C * 4,
+        # per (group, slice) block: the group's layer-1 partials + 16 rows of W2 + 16 columns of Wl; outputs
+        "proto_extend_fwd": G * nsl * (shot * nsl * C + 32 * C) * 4 + 3 * B * C * 4 + G * nsl * C * 4,
+        "classify_fwd": N * C * P * sF + K * C * 4 + G * nsl * C * 4 + N * K * C * 4 + N * K * P * 4 + NB * 2 * P * 4,
         "loss_pair_fwd": N * Q * 8 + N * K * P * 4 + 2 * N * K * P * 4 + NB * Q * 8 + NB * 2 * P * 4,
         "loss_finalize": (N + NB) * s.h * 8,
-        "bwd_dwn": N * C * P * sF + 2 * N * K * P * 4 + N * n_part * K * C * 4,
-        "bwd_chain_dfq": N * C * P * sF + 2 * N * K * P * 4 + N * K * C * 4 + 3 * C * C * 4 + 7 * B * C * 4,
-        "bwd_params_dfs": B * C * P * sF + B * P * 4 + 7 * B * C * 4 + N * n_part * K * C * 4 + 3 * C * C * 4,
+        # dWn slabs || dFq: Fq twice (once per role), the two gradient slabs twice, dFq out, slabs out
+        "bwd_dwn": 2 * N * C * P * sF + 4 * N * K * P * 4 + N * C * P * sF + N * n_part * K * C * 4 + N * K * C * 4,
+        # per (group, slice) block: the label row of every slab + 16 columns of Wl + 16 rows of W2; outputs
+        "bwd_chain_dfq": G * nsl * (n_part * C + 32 * C) * 4 + 2 * B * C * 4 + B * nsl * C * 4,
+        "bwd_params_dfs": B * C * P * sF + B * P * 4 + B * C * C * 4 + B * nsl * C * 4 + 6 * B * C * 4
+                          + N * n_part * K * C * 4 + 3 * C * C * 4,
     }
 
 

@@ -52,11 +52,21 @@ __device__ __forceinline__ void load2<unsigned short, false>(const unsigned shor
     b = pa + 1 < P ? bf16_to_f32(y) : 0.f;
 }
 
-template <typename T, int RT, int NLD>
+// BUILD (fused step, sliced chain): Wn[n] does not exist yet.  The block assembles it in LDS while it
+// stages the tile -- base rows = weight * weight_mask[n] (dropout, model/common.py:326), the rows the
+// episode's ways overwrite = bl + sum of the projection's split-K partials (model/common.py:327-334,
+// a later way wins a duplicate label) -- and the block of tile 0 writes it out for the backward pass.
+struct WnBuild {
+    const float *weight /*[K][C]*/, *weight_mask /*[N][K][C] or null*/, *proto_part /*[N*way][C/16][C]*/, *bl;
+    float* Wn_out /*[N][K][C]*/;
+};
+
+template <typename T, int RT, int NLD, bool BUILD>
 __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
                                                           int64_t wn_stride, const int64_t* __restrict__ labels,
                                                           int way, int K, int C, int P, int base,
-                                                          float* __restrict__ logits, float* __restrict__ bin) {
+                                                          float* __restrict__ logits, float* __restrict__ bin,
+                                                          WnBuild wb) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n = blockIdx.y, p0 = blockIdx.x * CL_TP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,9 +96,32 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     }
 #endif
 
+    // the rows this episode's ways overwrite: thread group jw = tid / 64 sums the partials of way jw
+    // (16-byte column pieces, all loads in flight together, fixed order)
+    constexpr int NSL = NLD / 2;                   // C / 16
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+    int prow = -1;
+    if constexpr (BUILD) {
+        const int jw = min(tid >> 6, way - 1), c4 = min(tid & 63, (C >> 2) - 1);
+        const int64_t* lab = labels + (int64_t)n * way;
+        const int64_t mine = lab[jw];
+        bool win = (tid >> 6) < way && (tid & 63) < (C >> 2) && mine >= 0 && mine < K;
+        for (int jj = jw + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
+        const float* pp = wb.proto_part + ((int64_t)(n * way + jw) * NSL) * C + c4 * 4;
+        f32x4 t[NSL];
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) t[q] = *reinterpret_cast<const f32x4*>(pp + (int64_t)q * C);
+        f32x4 acc4 = t[0];
+#pragma unroll
+        for (int q = 1; q < NSL; ++q) { acc4[0] += t[q][0]; acc4[1] += t[q][1]; acc4[2] += t[q][2]; acc4[3] += t[q][3]; }
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wb.bl + c4 * 4);
+        pv = f32x4{acc4[0] + b4[0], acc4[1] + b4[1], acc4[2] + b4[2], acc4[3] + b4[3]};
+        prow = win ? (int)mine * ldw + c4 * 4 : -1;
+    }
     // stage Wn[n] -> LDS [K][C+1]: 16-byte loads, all of a thread's loads issued before the first store
     {
-        const float* src = Wn + (int64_t)n * wn_stride;
+        const float* src = BUILD ? wb.weight : Wn + (int64_t)n * wn_stride;
+        const float* msk = (BUILD && wb.weight_mask) ? wb.weight_mask + (int64_t)n * K * C : nullptr;
         const int nv = (K * C) >> 2;
 #pragma unroll 1
         for (int base = 0; base < nv; base += 256 * 8) {
@@ -102,6 +135,16 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                 v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(i4, nv - 1) * 4);
 #endif
             }
+            if (BUILD && msk != nullptr) {
+                f32x4 m[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i4 = base + u * 256 + tid;
+                    m[u] = *reinterpret_cast<const f32x4*>(msk + (int64_t)min(i4, nv - 1) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u][0] *= m[u][0]; v[u][1] *= m[u][1]; v[u][2] *= m[u][2]; v[u][3] *= m[u][3]; }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i4 = base + u * 256 + tid;
@@ -112,6 +155,39 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                     d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
                 }
             }
+        }
+    }
+    if constexpr (BUILD) {
+        __syncthreads();
+        if (prow >= 0) {
+            float* d = sm + prow;
+            d[0] = pv[0]; d[1] = pv[1]; d[2] = pv[2]; d[3] = pv[3];
+        }
+        // more than 4 ways: the remaining ones, four at a time (winners own distinct rows)
+        for (int jw0 = 4; jw0 < way; jw0 += 4) {
+            const int jw = jw0 + (tid >> 6), c4 = tid & 63;
+            if (jw < way && c4 < (C >> 2)) {
+                const int64_t* lab = labels + (int64_t)n * way;
+                const int64_t mine = lab[jw];
+                bool win = mine >= 0 && mine < K;
+                for (int jj = jw + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
+                if (win) {
+                    const float* pp = wb.proto_part + ((int64_t)(n * way + jw) * NSL) * C + c4 * 4;
+                    f32x4 acc4 = *reinterpret_cast<const f32x4*>(pp);
+                    for (int q = 1; q < NSL; ++q) {
+                        const f32x4 tq = *reinterpret_cast<const f32x4*>(pp + (int64_t)q * C);
+                        acc4[0] += tq[0]; acc4[1] += tq[1]; acc4[2] += tq[2]; acc4[3] += tq[3];
+                    }
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(wb.bl + c4 * 4);
+                    float* d = sm + (int)mine * ldw + c4 * 4;
+                    d[0] = acc4[0] + b4[0]; d[1] = acc4[1] + b4[1]; d[2] = acc4[2] + b4[2]; d[3] = acc4[3] + b4[3];
+                }
+            }
+        }
+        if (blockIdx.x == 0) {
+            __syncthreads();
+            float* dst = wb.Wn_out + (int64_t)n * K * C;
+            for (int idx = tid; idx < K * C; idx += 256) dst[idx] = sm[(idx / C) * ldw + (idx % C)];
         }
     }
     __syncthreads();
@@ -251,10 +327,10 @@ static int set_lds(KernelT kern, size_t lds) {
     return denet_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
 }
 
-template <typename T>
+template <typename T, bool BUILD = false>
 static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, const int64_t* labels, int64_t N,
                                int64_t way, int64_t K, int64_t C, int64_t P, int base, float* logits, float* bin,
-                               hipStream_t st) {
+                               hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
     const size_t a = (size_t)K * (C + 1), b = (size_t)4 * K * CL_LD;
     const size_t lds = (a > b ? a : b) * 4;
@@ -262,10 +338,10 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
     dim3 grid((unsigned)((P + CL_TP - 1) / CL_TP), (unsigned)N), block(256);
 #define CL_FWD2(R, L)                                                                                       \
     {                                                                                                       \
-        int rc = set_lds(classify_fwd_kernel<T, R, L>, lds);                                                \
+        int rc = set_lds(classify_fwd_kernel<T, R, L, BUILD>, lds);                                         \
         if (rc) return rc;                                                                                  \
-        hipLaunchKernelGGL((classify_fwd_kernel<T, R, L>), grid, block, lds, st, Fq, Wn, wn_stride, labels, \
-                           (int)way, (int)K, (int)C, (int)P, base, logits, bin);                            \
+        hipLaunchKernelGGL((classify_fwd_kernel<T, R, L, BUILD>), grid, block, lds, st, Fq, Wn, wn_stride,  \
+                           labels, (int)way, (int)K, (int)C, (int)P, base, logits, bin, wb);                \
     }
 #define CL_FWD(R)                       \
     if (C == 64) CL_FWD2(R, 8) else CL_FWD2(R, 32)
@@ -296,6 +372,25 @@ extern "C" int denet_classify_fwd(const void* Fq, int feat_dtype, const float* W
     if (feat_dtype == DENET_BF16)
         return launch_classify_fwd<unsigned short>((const unsigned short*)Fq, Wn, K * C, labels, N, way, K, C, P,
                                                    base, logits, logits_binary, st);
+    return DENET_E_UNSUPPORTED;
+}
+
+// Fused step: classifier that assembles Wn[n] itself (see WnBuild) and writes it to Wn_out.
+int denet_classify_build_fwd(const void* Fq, int feat_dtype, const float* weight, const float* weight_mask,
+                             const float* proto_part, const float* bl, const int64_t* labels, int64_t N, int64_t way,
+                             int64_t K, int64_t C, int64_t P, float* Wn_out, float* logits, float* logits_binary,
+                             void* stream) {
+    if (!Fq || !weight || !proto_part || !bl || !labels || !Wn_out || !logits || !logits_binary) return DENET_E_BADARG;
+    if (!pos(N) || !pos(K) || !pos(C) || !pos(P) || !pos(way)) return DENET_E_BADARG;
+    if (!c_ok(C) || K > 128 || N > 65535) return DENET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WnBuild wb{weight, weight_mask, proto_part, bl, Wn_out};
+    if (feat_dtype == DENET_F32)
+        return launch_classify_fwd<float, true>((const float*)Fq, nullptr, 0, labels, N, way, K, C, P, 1, logits,
+                                                logits_binary, st, wb);
+    if (feat_dtype == DENET_BF16)
+        return launch_classify_fwd<unsigned short, true>((const unsigned short*)Fq, nullptr, 0, labels, N, way, K, C,
+                                                         P, 1, logits, logits_binary, st, wb);
     return DENET_E_UNSUPPORTED;
 }
 

@@ -32,10 +32,23 @@ template <typename T>
 __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, const int64_t* __restrict__ Ys,
                                                     float* __restrict__ mask, float* __restrict__ cnt,
                                                     float* __restrict__ S, int C, int P, int rows_per_block, int H,
-                                                    int W, int h, int w, int b, int cblk, float* sm) {
+                                                    int W, int h, int w, int b, int cblk, float* sm,
+                                                    const float* __restrict__ W1 = nullptr,
+                                                    float* __restrict__ pre1_part = nullptr) {
     const int c0 = cblk * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* mrow = mask + (int64_t)b * P;
+    // Sliced chain, first mat-vec (gate layer 1, model/common.py:226) as a split-K partial: this block
+    // owns att[c0..c0+16) of image b, so it can form  pre1_part[b][cblk][o] = sum_r W1[o][c0+r] * att[c0+r]
+    // for every output row o.  The 64-byte slice of W1 row o = tid is requested FIRST (it does not
+    // depend on anything), so it arrives under the feature stream.  rows_per_block is 16 here.
+    float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's channel sums
+    f32x4 w1v[4];
+    if (W1 != nullptr) {
+        const float* wp = W1 + (int64_t)min((int)threadIdx.x, C - 1) * C + c0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
+    }
     constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
@@ -85,7 +98,22 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int r = r0 + 4 * q;
-            if (r < rows_per_block && c0 + r < C && lane == 0) S[(int64_t)b * C + c0 + r] = accs[q];
+            if (r < rows_per_block && c0 + r < C && lane == 0) {
+                S[(int64_t)b * C + c0 + r] = accs[q];
+                if (W1 != nullptr) sl[r] = accs[q];
+            }
+        }
+    };
+    auto chain_tail = [&]() {
+        if (W1 == nullptr) return;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            const float Pf = (float)P;
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a = fmaf(w1v[t >> 2][t & 3], sl[t] / Pf, a);   // att = S / (h*w)
+            const int ncb = C / rows_per_block;
+            pre1_part[((int64_t)b * ncb + cblk) * C + threadIdx.x] = a;
         }
     };
     if (short_rows) issue(wave);
@@ -125,6 +153,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             issue(r);
             consume(r);
         }
+        chain_tail();
         return;
     }
     // ---- long rows: stream each row with a rolling loop
@@ -148,8 +177,12 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         }
         acc += (t0 + lane < P) ? tv1 * sm[min(t0 + lane, P - 1)] : 0.f;
         acc = wave_sum(acc);
-        if (lane == 0) S[(int64_t)b * C + c] = acc;
+        if (lane == 0) {
+            S[(int64_t)b * C + c] = acc;
+            if (W1 != nullptr) sl[r] = acc;
+        }
     }
+    chain_tail();
 }
 
 template <typename T>
@@ -157,28 +190,82 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
                                                             const int64_t* __restrict__ Ys,
                                                             float* __restrict__ mask, float* __restrict__ cnt,
                                                             float* __restrict__ S, int C, int P,
-                                                            int rows_per_block, int H, int W, int h, int w) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [P] (+ 4)
+                                                            int rows_per_block, int H, int W, int h, int w,
+                                                            const float* __restrict__ W1,
+                                                            float* __restrict__ pre1_part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [P] (+ 4 + 16)
     // 1-D grid of ncb * B blocks; the ncb channel blocks of an image are placed on one XCD (shared gather)
     const int ncb = (C + rows_per_block - 1) / rows_per_block;
     const int v = xcd_swizzle(blockIdx.x, gridDim.x);
-    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm);
+    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
+                           pre1_part);
 }
 
 // ---------------------------------------------------------------------------
 // K1b: dFs[b,c,p] = mask[b,p] * coef[b,c]
 // ---------------------------------------------------------------------------
-template <typename T>
+// Sliced chain, last step (fused step only): the block forms coef[b][c0..c0+16) itself from the
+// split-K partials of the previous launch,
+//   dpre1[b][j] = (hidden[b][j] > 0) * sum_sl dh_part[b][sl][j]             (relu backward)
+//   datt[b][c]  = sum_j W1[j][c] * dpre1[b][j]                                (W1^T mat-vec, column slice)
+//   coef[b][c]  = dpool[grp][c] * gate[b][c] / (cnt[b] + eps) + datt[b][c] / P
+// thread j holds the 64-byte slice W1[j][c0..c0+16); the 16 sums over j are wave reductions
+// combined through LDS in a fixed order.  Needs C <= 256 and rows_per_block == 16.
+struct CoefArgs {
+    const float *dh_part, *hidden, *W1, *dpool, *gate, *cnt;
+    int shot, nsl;
+    float Pf, eps;
+};
+
+template <typename T, bool SLICED>
 __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ mask, const float* __restrict__ coef,
                                                     T* __restrict__ dFs, int C, int P, int rows_per_block, int b,
-                                                    int cblk, float* sm) {
+                                                    int cblk, float* sm, const CoefArgs& ca) {
     const int c0 = cblk * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* mrow = mask + (int64_t)b * P;
+    float* red = sm + ((P + 3) & ~3);        // [4][16]
+    float* coefs = red + 64;                 // [16]
+    float prod[16];
+    float cg = 0.f, cd = 0.f, cc = 1.f;
+    if constexpr (SLICED) {
+        const int j = min((int)threadIdx.x, C - 1);
+        const bool live = (int)threadIdx.x < C;
+        const float* wp = ca.W1 + (int64_t)j * C + c0;
+        f32x4 w1v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
+        const float hid = ca.hidden[(int64_t)b * C + j];
+        const float* dp = ca.dh_part + (int64_t)b * ca.nsl * C + j;
+        float dh = 0.f;
+#pragma unroll 16
+        for (int q = 0; q < ca.nsl; ++q) dh += dp[(int64_t)q * C];
+        const float dpre = (live && hid > 0.f) ? dh : 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) prod[t] = w1v[t >> 2][t & 3] * dpre;
+        // factors of the first term, for the 16 finishing threads (requested now, used after the barrier)
+        const int t16 = threadIdx.x & 15;
+        cg = ca.gate[(int64_t)b * C + c0 + t16];
+        cd = ca.dpool[(int64_t)(b / ca.shot) * C + c0 + t16];
+        cc = ca.cnt[b] + ca.eps;
+    }
     // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
     // latency once per iteration)
 #pragma unroll 8
     for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
+    if constexpr (SLICED) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float v = wave_sum(prod[t]);
+            if (lane == t) red[wave * 16 + t] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int t = threadIdx.x;
+            const float datt = ((red[t] + red[16 + t]) + red[32 + t]) + red[48 + t];
+            coefs[t] = cd * (cg / cc) + datt / ca.Pf;
+        }
+    }
     __syncthreads();
 
     constexpr int V = Vec16<T>::N;
@@ -186,7 +273,7 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     for (int r = wave; r < rows_per_block; r += 4) {
         const int c = c0 + r;
         if (c >= C) break;
-        const float k = coef[(int64_t)b * C + c];
+        const float k = SLICED ? coefs[r] : coef[(int64_t)b * C + c];
         T* row = dFs + ((int64_t)b * C + c) * P;
         const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
         int head = mis ? V - mis : 0;
@@ -217,6 +304,6 @@ __global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __rest
                                                             T* __restrict__ dFs, int C, int P,
                                                             int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    masked_sum_bwd_body<T>(mask, coef, dFs, C, P, rows_per_block, blockIdx.y, blockIdx.x, sm);
+    masked_sum_bwd_body<T, false>(mask, coef, dFs, C, P, rows_per_block, blockIdx.y, blockIdx.x, sm, CoefArgs{});
 }
 

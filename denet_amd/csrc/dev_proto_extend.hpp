@@ -238,11 +238,14 @@ static __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* _
 // ---------------------------------------------------------------------------
 #define WG_ROWS 1
 struct PeParamsArgs {
+    // u1 = dpre1 [B,C]; in the sliced chain (dh_part != nullptr) it is not materialised: role 0 forms
+    // column o0 of it from the split-K partials dh_part [B][C/16][C] and the relu mask of `hidden`
     const float *u1, *u2, *u3, *S, *hidden, *pool, *dWn_part, *weight_mask;
     const int64_t* labels;
     int n_part, N, way, B, K, C;
     float Pf;
     float *dW1, *db1, *dW2, *db2, *dWl, *dbl, *dweight;
+    const float* dh_part = nullptr;
 };
 // blocks per role: roles 0..2 need C/WG_ROWS blocks, role 3 needs K * C/16
 __host__ __device__ __forceinline__ int pe_params_gx(int K, int C) {
@@ -319,6 +322,35 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
     const float vs = which == 0 ? 1.f / Pf : 1.f;
     float* dW = which == 0 ? dW1 : (which == 1 ? dW2 : dWl);
     float* db = which == 0 ? db1 : (which == 1 ? db2 : dbl);
+    if (which == 0 && a.dh_part != nullptr) {
+        // sliced chain: dpre1[b][o0] for 1024 images at a time in LDS, then the same row product
+        const float* __restrict__ dh_part = a.dh_part;
+        const int nsl = C >> 4;
+        float acc = 0.f, sdb = 0.f;                       // C <= 256: one output column per thread
+        for (int bb = 0; bb < B; bb += 1024) {
+            const int nb = min(1024, B - bb);
+            __syncthreads();
+            for (int b = tid; b < nb; b += 256) {
+                const float* dp = dh_part + ((int64_t)(bb + b) * nsl) * C + o0;
+                float t = 0.f;
+#pragma unroll 16
+                for (int q = 0; q < nsl; ++q) t += dp[(int64_t)q * C];
+                smem[b] = hidden[(int64_t)(bb + b) * C + o0] > 0.f ? t : 0.f;
+            }
+            __syncthreads();
+            if (tid < C) {
+#pragma unroll 16
+                for (int b = 0; b < nb; ++b) {
+                    const float u = smem[b];
+                    acc = fmaf(u, V[(int64_t)(bb + b) * C + tid], acc);
+                    sdb += u;
+                }
+            }
+        }
+        if (tid < C) dW[(int64_t)o0 * C + tid] = acc * vs;
+        if (tid == 0) db[o0] = sdb;
+        return;
+    }
     // One output row per block (WG_ROWS == 1).  U[b, o0] is the same address for every lane, so the
     // bias gradient db[o0] = sum_b U[b, o0] falls out of the same loads; 16 images in flight at a time.
     for (int i = tid; i < C; i += 256) {

@@ -4,6 +4,7 @@
 // one stream, with a caller-provided workspace and no host synchronisation
 // (the reference syncs N*way + 3 times per step: SURVEY.md §1).
 #include "denet_common.hpp"
+#include "dev_chain_sliced.hpp"
 #include "dev_classify.hpp"
 #include "dev_masked_sum.hpp"
 #include "dev_proto_extend.hpp"
@@ -11,7 +12,7 @@
 
 struct HeadWs {
     float *mask, *cnt, *S, *hidden, *gate, *pool, *Wn, *part_k, *part_p, *scale, *dlog_a, *dlog_b, *dWn_part,
-        *coef, *u;
+        *pre1_part, *proto_part, *dh_part, *dpool, *u2, *u3;
     int64_t total;   // bytes
 };
 
@@ -38,8 +39,12 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
     TAKE(dlog_a, N * K * P);
     TAKE(dlog_b, N * K * P);
     TAKE(dWn_part, N * n_part * K * C);
-    TAKE(coef, B * C);
-    TAKE(u, 3 * B * C + N * K * C);
+    TAKE(pre1_part, B * (C / 16) * C);       // sliced chain: split-K partials (dev_chain_sliced.hpp)
+    TAKE(proto_part, NB * (C / 16) * C);
+    TAKE(dh_part, B * (C / 16) * C);
+    TAKE(dpool, NB * C);
+    TAKE(u2, B * C);
+    TAKE(u3, B * C);
 #undef TAKE
     s.total = off * 4;
     return s;
@@ -49,41 +54,40 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
 // Fused launches of the backward half.  At batch 8 every kernel of the step is latency-bound
 // (5-30 us for a few MB), so the step time is the LENGTH of the dependency chain; independent
 // pieces therefore share a launch, block roles picked by blockIdx:
-//   B1  dWn slabs (K3b, first half)   [+ the loss reduction, in block (0,0), when deferred]
-//   B2  K2b chain (N*way blocks)  ||  dFq (K3b, second half: N*T blocks)      512 threads
-//   B3  K2b parameter gradients   ||  dFs = mask * coef (K1b)                  256 threads
+//   B1  dWn slabs (K3b, first half)  ||  dFq (K3b, second half)   [+ the loss reduction, in block (0,0)]
+//   B2  sliced chain, middle: dproto -> dpool -> dz -> split-K partials of W2^T dz     (tiny)
+//   B3  K2b parameter gradients   ||  coef + dFs = mask * coef (K1b)
 // ---------------------------------------------------------------------------
 template <typename T, int RT>
-__global__ __launch_bounds__(256) void head_bwd_dwn_kernel(ClsBwdArgs g, const float* __restrict__ part_p, int NB,
-                                                          int parts_p, float* __restrict__ losses) {
+__global__ __launch_bounds__(256) void head_bwd_dwn_kernel(ClsBwdArgs g, ClsBwdArgs g2, const float* __restrict__ part_p,
+                                                          int NB, int parts_p, float* __restrict__ losses) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    classify_bwd_body<T, RT, 4>(g, blockIdx.y, blockIdx.x, sm);
-    if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
-        __syncthreads();
-        loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
+    const int n_part = g.n_part;
+    if ((int)blockIdx.x < n_part) {
+        classify_bwd_body<T, RT, 4>(g, blockIdx.y, blockIdx.x, sm);
+        if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+            __syncthreads();
+            loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
+        }
+    } else {
+        classify_bwd_body<T, RT, 4>(g2, blockIdx.y, blockIdx.x - n_part, sm);
     }
 }
 
-template <typename T, int RT, int C, int CH>
-__global__ __launch_bounds__(512) void head_bwd_mid_kernel(PeChainArgs ch, ClsBwdArgs g, int groups, int n_tiles) {
+template <int CJ, int NS>
+__global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bx = blockIdx.x;
-    if (bx < groups) {
-        proto_extend_bwd_chain_body<C, CH>(ch, bx, sm);
-    } else {
-        const int r = bx - groups;
-        classify_bwd_body<T, RT, 8>(g, r / n_tiles, r % n_tiles, sm);
-    }
+    constexpr int NSL = 64 * CJ / SC_SL;
+    chain_mid_bwd_body<CJ, NS>(a, blockIdx.x / NSL, blockIdx.x % NSL, sm);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, const float* __restrict__ mask,
-                                                           const float* __restrict__ coef, T* __restrict__ dFs, int C,
-                                                           int P, int rpb, int ncb, int gx) {
+__global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, CoefArgs ca, const float* __restrict__ mask,
+                                                           T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bx = blockIdx.x, nms = gridDim.x - 4 * gx;
     if (bx < nms) {
-        masked_sum_bwd_body<T>(mask, coef, dFs, C, P, rpb, bx / ncb, bx % ncb, sm);
+        masked_sum_bwd_body<T, true>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
     } else {
         const int r = bx - nms;
         proto_extend_bwd_params_body(pa, r / gx, r % gx, sm);
@@ -91,35 +95,57 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, con
 }
 
 template <typename T, int RT>
-static int launch_bwd_dwn(const ClsBwdArgs& g, const float* part_p, int NB, int parts_p, float* losses, int n_part,
-                          int N, hipStream_t st) {
-    hipLaunchKernelGGL((head_bwd_dwn_kernel<T, RT>), dim3((unsigned)n_part, (unsigned)N), dim3(256), CLS_BWD_LDS(g.K),
-                       st, g, part_p, NB, parts_p, losses);
+static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
+                          float* losses, int n_part, int N, hipStream_t st) {
+    hipLaunchKernelGGL((head_bwd_dwn_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N), dim3(256),
+                       CLS_BWD_LDS(g.K), st, g, g2, part_p, NB, parts_p, losses);
     return DENET_OK;
 }
 
-template <typename T, int RT>
-static int launch_bwd_mid(const PeChainArgs& ch, const ClsBwdArgs& g, int groups, int n_tiles, int N, hipStream_t st) {
-    const size_t l0 = PE_CHAIN_LDS(g.C), l1 = CLS_BWD_LDS(g.K);
-    size_t lds = l0 > l1 ? l0 : l1;
-    // When the whole grid fits on the chip one block per CU, ask for more than half a CU's LDS so that
-    // no two blocks share a CU: the chain blocks (the long pole: 768 KB of weights from L2 through ONE
-    // CU each) then never compete with a dFq block for their CU's memory pipeline.
-    if (groups + N * n_tiles <= 256 && lds < 82 * 1024) lds = 82 * 1024;
-    dim3 grid((unsigned)(groups + N * n_tiles)), block(512);
-    if (g.C == 256) {
-        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_mid_kernel<T, RT, 256, 16>), lds))
-            return DENET_E_LAUNCH;
-        hipLaunchKernelGGL((head_bwd_mid_kernel<T, RT, 256, 16>), grid, block, lds, st, ch, g, groups, n_tiles);
-    } else if (g.C == 64) {
-        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_mid_kernel<T, RT, 64, 8>), lds))
-            return DENET_E_LAUNCH;
-        hipLaunchKernelGGL((head_bwd_mid_kernel<T, RT, 64, 8>), grid, block, lds, st, ch, g, groups, n_tiles);
-    } else {
-        return DENET_E_UNSUPPORTED;
-    }
+static int launch_bwd_mid(const ChainMidArgs& a, int groups, int C, int shot, hipStream_t st) {
+    const int nsl = C / SC_SL;
+    dim3 grid((unsigned)(groups * nsl)), block(SC_THREADS);
+#define CM_GO(CJ, NS) hipLaunchKernelGGL((head_bwd_mid_kernel<CJ, NS>), grid, block, SC_CM_LDS, st, a)
+#define CM_NS(CJ)                     \
+    if (shot == 1) CM_GO(CJ, 1);      \
+    else if (shot <= 3) CM_GO(CJ, 3); \
+    else if (shot <= 5) CM_GO(CJ, 5); \
+    else CM_GO(CJ, 8)
+    if (C == 256) { CM_NS(4); }
+    else if (C == 64) { CM_NS(1); }
+    else return DENET_E_UNSUPPORTED;
+#undef CM_NS
+#undef CM_GO
     return DENET_OK;
 }
+
+static int launch_gate_proj(const GateProjArgs& a, int groups, int C, int shot, hipStream_t st) {
+    const int nsl = C / SC_SL;
+    dim3 grid((unsigned)(groups * nsl)), block(SC_THREADS);
+    const size_t lds = SC_GP_LDS(C);
+#define GP_GO(CJ, NS) hipLaunchKernelGGL((gate_proj_kernel<CJ, NS>), grid, block, lds, st, a)
+#define GP_NS(CJ)                     \
+    if (shot == 1) GP_GO(CJ, 1);      \
+    else if (shot <= 3) GP_GO(CJ, 3); \
+    else if (shot <= 5) GP_GO(CJ, 5); \
+    else GP_GO(CJ, 8)
+    if (C == 256) { GP_NS(4); }
+    else if (C == 64) { GP_NS(1); }
+    else return DENET_E_UNSUPPORTED;
+#undef GP_NS
+#undef GP_GO
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+// internal launchers of the sliced chain's forward neighbours (masked_sum.hip, classify.hip)
+int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Ys, int64_t B, int64_t C, int64_t H,
+                                int64_t W, int64_t h, int64_t w, float* mask, float* cnt, float* S, const float* W1,
+                                float* pre1_part, void* stream);
+int denet_classify_build_fwd(const void* Fq, int feat_dtype, const float* weight, const float* weight_mask,
+                             const float* proto_part, const float* bl, const int64_t* labels, int64_t N, int64_t way,
+                             int64_t K, int64_t C, int64_t P, float* Wn_out, float* logits, float* logits_binary,
+                             void* stream);
 
 #define RT_DISPATCH(fn, T, RT, ...)                                \
     ((RT) == 1 ? fn<T, 1>(__VA_ARGS__) : (RT) == 2 ? fn<T, 2>(__VA_ARGS__) \
@@ -170,13 +196,19 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
     const int64_t B = N * way * shot, P = h * w, NB = N * way;
     // the grad and no-grad variants of the CE kernel may tile the columns differently
     const int64_t pk_run = with_grad ? pk : denet_upsample_loss_parts(K, h, w, H, W, 0);
+    if (!(C == 64 || C == 256) || K > 128 || shot > 8) return DENET_E_UNSUPPORTED;
+    if (!Fq || !Fs || !Ys || !labels || !weight || !W1 || !b1 || !W2 || !b2 || !Wl || !bl) return DENET_E_BADARG;
     PROBED(DENET_K_MASKED_SUM_FWD,
-           denet_masked_pool_fwd(Fs, feat_dtype, Ys, B, C, H, W, h, w, s.mask, s.cnt, s.S, stream));
-    PROBED(DENET_K_PROTO_EXTEND_FWD,
-           denet_proto_extend_fwd(s.S, s.cnt, W1, b1, W2, b2, Wl, bl, weight, labels, gate_mask, weight_mask, N, way,
-                                  shot, K, C, P, s.hidden, s.gate, s.pool, s.Wn, nullptr, stream));
+           denet_masked_pool_fwd_chain(Fs, feat_dtype, Ys, B, C, H, W, h, w, s.mask, s.cnt, s.S, W1, s.pre1_part,
+                                       stream));
+    {
+        GateProjArgs ga{s.pre1_part, s.S, s.cnt, b1, W2, b2, Wl, gate_mask, (int)shot, s.hidden, s.gate, s.pool,
+                        s.proto_part};
+        PROBED(DENET_K_PROTO_EXTEND_FWD, launch_gate_proj(ga, (int)NB, (int)C, (int)shot, (hipStream_t)stream));
+    }
     PROBED(DENET_K_CLASSIFY_FWD,
-           denet_classify_fwd(Fq, feat_dtype, s.Wn, labels, N, way, K, C, P, 1, logits_full, logits_binary, stream));
+           denet_classify_build_fwd(Fq, feat_dtype, weight, weight_mask, s.proto_part, bl, labels, N, way, K, C, P,
+                                    s.Wn, logits_full, logits_binary, stream));
     if (Yq_full && Yq) {
         PROBED(DENET_K_WCE_FWD,
                denet_loss_pair_fwd(logits_full, Yq_full, wgt, logits_binary, Yq, N, NB, K, h, w, H, W, 0.25f, 2.f,
@@ -221,54 +253,54 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     const int RT = (int)((K + 31) / 32);
     const bool f32 = feat_dtype == DENET_F32;
     hipStream_t st = (hipStream_t)stream;
-    float *u1 = s.u, *u2 = u1 + B * C, *u3 = u2 + B * C;
 
-    // B1: dWn slabs; scale[n] is derived from the loss partials inside the kernel
+    // B1: dWn slabs || dFq; scale[n] is derived from the loss partials inside the kernel
     ClsBwdArgs g{Fq, s.Wn, s.dlog_a, s.dlog_b, nullptr, grad_loss_k, s.part_k, (int)pk, (int)N, (int)K, (int)C,
                  (int)P, n_part, nullptr, s.dWn_part, s.scale};
     {
-        const bool on = probe && probe->which == DENET_K_CLASSIFY_BWD && probe->start && probe->stop;
-        if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        const float* pp_ptr = have_focal ? s.part_p : nullptr;
-        int rc = f32 ? RT_DISPATCH(launch_bwd_dwn, float, RT, g, pp_ptr, (int)NB, (int)pp, losses, n_part, (int)N, st)
-                     : RT_DISPATCH(launch_bwd_dwn, unsigned short, RT, g, pp_ptr, (int)NB, (int)pp, losses, n_part,
-                                   (int)N, st);
-        if (rc) return rc;
-        DENET_CHECK_LAUNCH();
-        if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
-    }
-    // B2: chain || dFq
-    {
-        PeChainArgs ch{s.dWn_part, s.S, s.cnt, s.hidden, s.gate, W1, W2, Wl, gate_mask, labels, n_part, (int)way,
-                       (int)shot, (int)K, (float)P, u1, u2, u3, s.coef};
         ClsBwdArgs g2 = g;
         g2.dFq = dFq;
         g2.dWn_part = nullptr;
         g2.scale_out = nullptr;
-        const bool on = probe && probe->which == DENET_K_PE_BWD_CHAIN && probe->start && probe->stop;
+        const bool on = probe && probe->which == DENET_K_CLASSIFY_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        int rc = f32 ? RT_DISPATCH(launch_bwd_mid, float, RT, ch, g2, (int)(N * way), n_part, (int)N, st)
-                     : RT_DISPATCH(launch_bwd_mid, unsigned short, RT, ch, g2, (int)(N * way), n_part, (int)N, st);
+        const float* pp_ptr = have_focal ? s.part_p : nullptr;
+        int rc = f32 ? RT_DISPATCH(launch_bwd_dwn, float, RT, g, g2, pp_ptr, (int)NB, (int)pp, losses, n_part, (int)N,
+                                   st)
+                     : RT_DISPATCH(launch_bwd_dwn, unsigned short, RT, g, g2, pp_ptr, (int)NB, (int)pp, losses,
+                                   n_part, (int)N, st);
         if (rc) return rc;
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
-    // B3: parameter gradients || dFs
+    // B2: sliced chain, middle
     {
-        PeParamsArgs pa{u1, u2, u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N, (int)way,
-                        (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight};
+        ChainMidArgs cm{s.dWn_part, s.S, s.cnt, s.gate, gate_mask, Wl, W2, labels, n_part, (int)way, (int)shot,
+                        (int)K, s.u2, s.u3, s.dpool, s.dh_part};
+        const bool on = probe && probe->which == DENET_K_PE_BWD_CHAIN && probe->start && probe->stop;
+        if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
+        int rc = launch_bwd_mid(cm, (int)NB, (int)C, (int)shot, st);
+        if (rc) return rc;
+        DENET_CHECK_LAUNCH();
+        if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
+    }
+    // B3: parameter gradients || coef + dFs
+    {
+        PeParamsArgs pa{nullptr, s.u2, s.u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N,
+                        (int)way, (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part};
+        CoefArgs ca{s.dh_part, s.hidden, W1, s.dpool, s.gate, s.cnt, (int)shot, (int)(C / 16), (float)P, SC_EPS};
         const int gx = pe_params_gx((int)K, (int)C);
-        const int rpb = C >= 16 ? 16 : (int)C, ncb = (int)((C + rpb - 1) / rpb);
-        size_t lds = (size_t)P * 4;
+        const int rpb = 16, ncb = (int)(C / 16);
+        size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;
         if (lds < 4096) lds = 4096;
         dim3 grid((unsigned)(4 * gx + B * ncb)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
         if (f32)
-            hipLaunchKernelGGL(head_bwd_tail_kernel<float>, grid, block, lds, st, pa, s.mask, s.coef, (float*)dFs,
-                               (int)C, (int)P, rpb, ncb, gx);
+            hipLaunchKernelGGL(head_bwd_tail_kernel<float>, grid, block, lds, st, pa, ca, s.mask, (float*)dFs, (int)C,
+                               (int)P, rpb, ncb, gx);
         else
-            hipLaunchKernelGGL(head_bwd_tail_kernel<unsigned short>, grid, block, lds, st, pa, s.mask, s.coef,
+            hipLaunchKernelGGL(head_bwd_tail_kernel<unsigned short>, grid, block, lds, st, pa, ca, s.mask,
                                (unsigned short*)dFs, (int)C, (int)P, rpb, ncb, gx);
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;

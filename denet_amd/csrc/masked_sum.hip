@@ -61,15 +61,15 @@ extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float*
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
-    size_t lds = (size_t)P * 4 + 32;
+    size_t lds = (size_t)P * 4 + 32 + 64;
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
                            (const float*)Fs, (const int64_t*)nullptr, (float*)mask, (float*)nullptr, S, (int)C,
-                           (int)P, rpb, 0, 0, 0, 0);
+                           (int)P, rpb, 0, 0, 0, 0, (const float*)nullptr, (float*)nullptr);
     else if (feat_dtype == DENET_BF16)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream,
                            (const unsigned short*)Fs, (const int64_t*)nullptr, (float*)mask, (float*)nullptr, S,
-                           (int)C, (int)P, rpb, 0, 0, 0, 0);
+                           (int)C, (int)P, rpb, 0, 0, 0, 0, (const float*)nullptr, (float*)nullptr);
     else
         return DENET_E_UNSUPPORTED;
     DENET_CHECK_LAUNCH();
@@ -97,28 +97,39 @@ extern "C" int denet_masked_sum_bwd(const float* mask, const float* coef, int64_
 }
 
 // K0 + K1 in one launch: the mask is gathered from Ys inside the pooling kernel (and written out,
-// with cnt, by the first channel block of every image for the backward pass).
-extern "C" int denet_masked_pool_fwd(const void* Fs, int feat_dtype, const int64_t* Ys, int64_t B, int64_t C,
-                                     int64_t H, int64_t W, int64_t h, int64_t w, float* mask, float* cnt, float* S,
-                                     void* stream) {
+// with cnt, by the first channel block of every image for the backward pass).  With W1 != nullptr
+// (sliced chain of the fused step; C must be a multiple of 16 and <= 256) every block also writes
+// its split-K partial of the first gate layer: pre1_part [B][C/16][C].
+int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Ys, int64_t B, int64_t C, int64_t H,
+                                int64_t W, int64_t h, int64_t w, float* mask, float* cnt, float* S, const float* W1,
+                                float* pre1_part, void* stream) {
     if (!Fs || !Ys || !mask || !cnt || !S) return DENET_E_BADARG;
+    if ((W1 == nullptr) != (pre1_part == nullptr)) return DENET_E_BADARG;
     if (!fits_int(B) || !fits_int(C) || !fits_int(H) || !fits_int(W) || !fits_int(h) || !fits_int(w) ||
         !fits_int(h * w) || !fits_int(H * W))
         return DENET_E_BADARG;
     const int64_t P = h * w;
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
+    if (W1 && ((C & 15) || C > 256)) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
-    size_t lds = (size_t)P * 4 + 32;
+    size_t lds = (size_t)P * 4 + 32 + 64;
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
-                           (const float*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w);
+                           (const float*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w,
+                           W1, pre1_part);
     else if (feat_dtype == DENET_BF16)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream,
                            (const unsigned short*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h,
-                           (int)w);
+                           (int)w, W1, pre1_part);
     else
         return DENET_E_UNSUPPORTED;
     DENET_CHECK_LAUNCH();
     return DENET_OK;
+}
+
+extern "C" int denet_masked_pool_fwd(const void* Fs, int feat_dtype, const int64_t* Ys, int64_t B, int64_t C,
+                                     int64_t H, int64_t W, int64_t h, int64_t w, float* mask, float* cnt, float* S,
+                                     void* stream) {
+    return denet_masked_pool_fwd_chain(Fs, feat_dtype, Ys, B, C, H, W, h, w, mask, cnt, S, nullptr, nullptr, stream);
 }
