@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdenet_hip.so")
+# DENET_HIP_LIB: another build of the same library (kernel A/B experiments); never a different backend
+LIB_PATH = os.environ.get("DENET_HIP_LIB") or os.path.join(_HERE, "libdenet_hip.so")
 
 F32, BF16 = 0, 1
 

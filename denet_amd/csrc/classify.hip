@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     {
         const float* src = BUILD ? wb.weight : Wn + (int64_t)n * wn_stride;
         const float* msk = (BUILD && wb.weight_mask) ? wb.weight_mask + (int64_t)n * K * C : nullptr;
+        const int64_t* lab = labels + (int64_t)n * way;
         const int nv = (K * C) >> 2;
 #pragma unroll 1
         for (int base = 0; base < nv; base += 256 * 8) {
@@ -151,14 +152,18 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                 if (i4 < nv) {
                     const int idx = i4 * 4;
                     const int k = idx / C, c = idx - k * C;
-                    float* d = sm + k * ldw + c;
-                    d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+                    bool keep = true;                 // BUILD: the rows a way overwrites are written below
+                    if constexpr (BUILD)
+                        for (int jj = 0; jj < way; ++jj) keep = keep && (lab[jj] != k);
+                    if (keep) {
+                        float* d = sm + k * ldw + c;
+                        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+                    }
                 }
             }
         }
     }
     if constexpr (BUILD) {
-        __syncthreads();
         if (prow >= 0) {
             float* d = sm + prow;
             d[0] = pv[0]; d[1] = pv[1]; d[2] = pv[2]; d[3] = pv[3];
@@ -184,14 +189,15 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                 }
             }
         }
-        if (blockIdx.x == 0) {
-            __syncthreads();
-            float* dst = wb.Wn_out + (int64_t)n * K * C;
-            for (int idx = tid; idx < K * C; idx += 256) dst[idx] = sm[(idx / C) * ldw + (idx % C)];
-        }
     }
     __syncthreads();
     STAMP(1);
+    if constexpr (BUILD) {
+        // Wn[n] for the backward pass: tile t writes rows t, t + tiles, ... (one 1 KB row = one store per thread)
+        float* dst = wb.Wn_out + (int64_t)n * K * C;
+        for (int k = blockIdx.x; k < K; k += gridDim.x)
+            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
+    }
 
     f32x16 acc[RT][2];
 #pragma unroll

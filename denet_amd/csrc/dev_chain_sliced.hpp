@@ -187,8 +187,15 @@ __device__ __forceinline__ void chain_mid_bwd_body(const ChainMidArgs& a, int gr
     {
         const int64_t row = win ? mine : 0;
         const float* src = a.dWn_part + (((int64_t)n * a.n_part) * K + row) * C + o;
-#pragma unroll 16
-        for (int qn = 0; qn < a.n_part; ++qn) dp += src[(int64_t)qn * K * C];
+        // 16 slabs at a time, clamped unconditional loads + select: a remainder loop would pay one
+        // memory round trip per slab
+        for (int q0 = 0; q0 < a.n_part; q0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)min(q0 + u, a.n_part - 1) * K * C];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dp += (q0 + u < a.n_part) ? v[u] : 0.f;
+        }
         dp = (win && live) ? dp / (float)ns : 0.f;
     }
     if (sl == 0 && live)

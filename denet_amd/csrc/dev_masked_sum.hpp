@@ -42,13 +42,8 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     // owns att[c0..c0+16) of image b, so it can form  pre1_part[b][cblk][o] = sum_r W1[o][c0+r] * att[c0+r]
     // for every output row o.  The 64-byte slice of W1 row o = tid is requested FIRST (it does not
     // depend on anything), so it arrives under the feature stream.  rows_per_block is 16 here.
-    float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's channel sums
+    float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's att = S / (h*w)
     f32x4 w1v[4];
-    if (W1 != nullptr) {
-        const float* wp = W1 + (int64_t)min((int)threadIdx.x, C - 1) * C + c0;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
-    }
     constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
@@ -100,7 +95,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             const int r = r0 + 4 * q;
             if (r < rows_per_block && c0 + r < C && lane == 0) {
                 S[(int64_t)b * C + c0 + r] = accs[q];
-                if (W1 != nullptr) sl[r] = accs[q];
+                if (W1 != nullptr) sl[r] = accs[q] / (float)P;        // att = S / (h*w)
             }
         }
     };
@@ -108,15 +103,19 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         if (W1 == nullptr) return;
         __syncthreads();
         if ((int)threadIdx.x < C) {
-            const float Pf = (float)P;
             float a = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) a = fmaf(w1v[t >> 2][t & 3], sl[t] / Pf, a);   // att = S / (h*w)
+            for (int t = 0; t < 16; ++t) a = fmaf(w1v[t >> 2][t & 3], sl[t], a);
             const int ncb = C / rows_per_block;
             pre1_part[((int64_t)b * ncb + cblk) * C + threadIdx.x] = a;
         }
     };
     if (short_rows) issue(wave);
+    if (W1 != nullptr) {                                   // behind the feature loads in the queue
+        const float* wp = W1 + (int64_t)min((int)threadIdx.x, C - 1) * C + c0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
+    }
 
     // ---- the mask: gathered here from the int64 label map (K0 fused: nearest resize,
     // model/common.py:189-190; the block with cblk == 0 also writes mask[b,:] and cnt[b] for the backward
@@ -179,7 +178,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         acc = wave_sum(acc);
         if (lane == 0) {
             S[(int64_t)b * C + c] = acc;
-            if (W1 != nullptr) sl[r] = acc;
+            if (W1 != nullptr) sl[r] = acc / (float)P;
         }
     }
     chain_tail();
@@ -217,7 +216,7 @@ struct CoefArgs {
     float Pf, eps;
 };
 
-template <typename T, bool SLICED>
+template <typename T, int NSLT>      // NSLT = C/16 for the sliced chain, 0: coef is given
 __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ mask, const float* __restrict__ coef,
                                                     T* __restrict__ dFs, int C, int P, int rows_per_block, int b,
                                                     int cblk, float* sm, const CoefArgs& ca) {
@@ -226,39 +225,46 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     const float* mrow = mask + (int64_t)b * P;
     float* red = sm + ((P + 3) & ~3);        // [4][16]
     float* coefs = red + 64;                 // [16]
-    float prod[16];
-    float cg = 0.f, cd = 0.f, cc = 1.f;
+    constexpr bool SLICED = NSLT > 0;
+    // every global load of the block is requested before the first wait: the coef operands and the
+    // mask row (8 clamped loads per thread cover P <= 2048; longer rows finish in a loop below)
+    f32x4 w1v[4];
+    float dhv[SLICED ? NSLT : 1];
+    float hid = 0.f, cg = 0.f, cd = 0.f, cc = 1.f;
     if constexpr (SLICED) {
         const int j = min((int)threadIdx.x, C - 1);
-        const bool live = (int)threadIdx.x < C;
         const float* wp = ca.W1 + (int64_t)j * C + c0;
-        f32x4 w1v[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
-        const float hid = ca.hidden[(int64_t)b * C + j];
-        const float* dp = ca.dh_part + (int64_t)b * ca.nsl * C + j;
-        float dh = 0.f;
-#pragma unroll 16
-        for (int q = 0; q < ca.nsl; ++q) dh += dp[(int64_t)q * C];
-        const float dpre = (live && hid > 0.f) ? dh : 0.f;
+        hid = ca.hidden[(int64_t)b * C + j];
+        const float* dp = ca.dh_part + (int64_t)b * NSLT * C + j;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) prod[t] = w1v[t >> 2][t & 3] * dpre;
-        // factors of the first term, for the 16 finishing threads (requested now, used after the barrier)
+        for (int q = 0; q < NSLT; ++q) dhv[q] = dp[(int64_t)q * C];
+        // factors of the first term, for the 16 finishing threads
         const int t16 = threadIdx.x & 15;
         cg = ca.gate[(int64_t)b * C + c0 + t16];
         cd = ca.dpool[(int64_t)(b / ca.shot) * C + c0 + t16];
         cc = ca.cnt[b] + ca.eps;
     }
-    // batched: 8 independent loads in flight per thread (an un-unrolled copy loop pays the memory
-    // latency once per iteration)
-#pragma unroll 8
-    for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
+    float mv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mv[u] = mrow[min((int)threadIdx.x + 256 * u, P - 1)];
     if constexpr (SLICED) {
+        float dh = 0.f;
+#pragma unroll
+        for (int q = 0; q < NSLT; ++q) dh += dhv[q];
+        const float dpre = ((int)threadIdx.x < C && hid > 0.f) ? dh : 0.f;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float v = wave_sum(prod[t]);
+            const float v = wave_sum(w1v[t >> 2][t & 3] * dpre);
             if (lane == t) red[wave * 16 + t] = v;
         }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if ((int)threadIdx.x + 256 * u < P) sm[threadIdx.x + 256 * u] = mv[u];
+    for (int p = threadIdx.x + 2048; p < P; p += 256) sm[p] = mrow[p];
+    if constexpr (SLICED) {
         __syncthreads();
         if (threadIdx.x < 16) {
             const int t = threadIdx.x;
@@ -304,6 +310,6 @@ __global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __rest
                                                             T* __restrict__ dFs, int C, int P,
                                                             int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    masked_sum_bwd_body<T, false>(mask, coef, dFs, C, P, rows_per_block, blockIdx.y, blockIdx.x, sm, CoefArgs{});
+    masked_sum_bwd_body<T, 0>(mask, coef, dFs, C, P, rows_per_block, blockIdx.y, blockIdx.x, sm, CoefArgs{});
 }
 

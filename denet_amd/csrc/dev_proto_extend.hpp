@@ -333,8 +333,13 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
             for (int b = tid; b < nb; b += 256) {
                 const float* dp = dh_part + ((int64_t)(bb + b) * nsl) * C + o0;
                 float t = 0.f;
-#pragma unroll 16
-                for (int q = 0; q < nsl; ++q) t += dp[(int64_t)q * C];
+                for (int q0 = 0; q0 < nsl; q0 += 16) {       // clamped unconditional loads + select
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = dp[(int64_t)min(q0 + u, nsl - 1) * C];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t += (q0 + u < nsl) ? v[u] : 0.f;
+                }
                 smem[b] = hidden[(int64_t)(bb + b) * C + o0] > 0.f ? t : 0.f;
             }
             __syncthreads();

@@ -112,6 +112,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     const int ys = first_dst_ge(py, sy, h, H), ye = first_dst_ge(py + 1, sy, h, H);
     const int rows = ye - ys;
 
+    STAMP(0);
     const float* src = logits + (int64_t)n * K * h * w;
 #pragma unroll 4
     for (int idx = tid; idx < K * ncol; idx += UL_T) {
@@ -122,6 +123,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     for (int k = tid; k < K; k += UL_T) wg[k] = (MODE == 0 && wgt) ? wgt[(int64_t)n * K + k] : 1.f;
     for (int c = tid; c <= ncell; c += UL_T) xs[c] = first_dst_ge(cell_lo + c, sx, w, W);
     __syncthreads();
+    STAMP(1);
     const int xbase = xs[0], xw = xs[ncell] - xbase;      // label columns needed
     {
         const int64_t* Yn = Y + (int64_t)n * H * W + (int64_t)ys * W + xbase;
@@ -139,6 +141,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // ---------------- phase 1 ----------------
     float num = 0.f, den = 0.f;
@@ -238,6 +241,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             }
         }
     }
+    STAMP(3);
     const float tn = block_sum_256(num, red);
     const float td = block_sum_256(den, red);
     if (tid == 0) {
@@ -247,6 +251,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     }
     if (!GRAD) return;
     __syncthreads();
+    STAMP(4);
 
     // ---------------- phase 2 ----------------
     const int rmid = (rows + 1) >> 1;
@@ -287,6 +292,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
         const int o = rh * kc + k * ncmax + cl;
         gl0[o] = L0; gl1[o] = L1; gr0[o] = R0; gr1[o] = R1;
     }
+    STAMP(5);
     __syncthreads();
     {
         float* da = dlog_a + (int64_t)n * K * h * w;
@@ -308,6 +314,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             if (py == 0) db[((int64_t)k * h) * w + x] = 0.f;
         }
     }
+    STAMP(6);
 }
 
 template <int MODE, bool GRAD>
@@ -318,14 +325,21 @@ __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
 
 // Weighted CE (blockIdx.y < N0) and binary focal (the rest) in ONE launch: the two losses read
 // different logit tensors and label maps and are independent, so their blocks run side by side.
+// Per-block time stamps (scripts/diag/loss_stamps.hip, C2 batch 8): the kernel is bound by VALU issue;
+// the CE blocks fill 4 of the 5 slots a CU has at 85 VGPRs and finish 18-30 us after the launch, the
+// focal blocks run in the fifth slot and in the slots CE blocks free.  Measured slower: the focal
+// tiles inside the CE blocks (42 us), 6 or 8 waves per SIMD by capping registers (spills), four row
+// groups in phase 2 (LDS then limits a CU to 4 blocks), a cell-level soft-max shift in phase 1.
 template <bool GRAD>
 __global__ __launch_bounds__(UL_T) void upsample_loss_pair_kernel(LossArgs g0, LossArgs g1, int N0, int nb0, int nb1) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    BSTAMP(0);
     if ((int)blockIdx.y < N0) {
         if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD>(g0, blockIdx.y, blockIdx.x, sm);
     } else {
         if ((int)blockIdx.x < nb1) upsample_loss_body<1, false>(g1, blockIdx.y - N0, blockIdx.x, sm);
     }
+    BSTAMP(1);
 }
 
 // loss_k = mean_n num_n/den_n ; loss_p = sum num / sum den ; scale[n] = 1/(N*den_n)

@@ -81,13 +81,13 @@ __global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a
     chain_mid_bwd_body<CJ, NS>(a, blockIdx.x / NSL, blockIdx.x % NSL, sm);
 }
 
-template <typename T>
+template <typename T, int NSLT>
 __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, CoefArgs ca, const float* __restrict__ mask,
                                                            T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bx = blockIdx.x, nms = gridDim.x - 4 * gx;
     if (bx < nms) {
-        masked_sum_bwd_body<T, true>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
+        masked_sum_bwd_body<T, NSLT>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
     } else {
         const int r = bx - nms;
         proto_extend_bwd_params_body(pa, r / gx, r % gx, sm);
@@ -296,12 +296,15 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
         dim3 grid((unsigned)(4 * gx + B * ncb)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        if (f32)
-            hipLaunchKernelGGL(head_bwd_tail_kernel<float>, grid, block, lds, st, pa, ca, s.mask, (float*)dFs, (int)C,
-                               (int)P, rpb, ncb, gx);
-        else
-            hipLaunchKernelGGL(head_bwd_tail_kernel<unsigned short>, grid, block, lds, st, pa, ca, s.mask,
-                               (unsigned short*)dFs, (int)C, (int)P, rpb, ncb, gx);
+#define TAIL_GO(TT, NSLT)                                                                                     \
+    hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, (int)C, \
+                       (int)P, rpb, ncb, gx)
+        if (f32) {
+            if (C == 256) TAIL_GO(float, 16); else TAIL_GO(float, 4);
+        } else {
+            if (C == 256) TAIL_GO(unsigned short, 16); else TAIL_GO(unsigned short, 4);
+        }
+#undef TAIL_GO
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
