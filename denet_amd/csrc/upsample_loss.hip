@@ -87,7 +87,7 @@ static int set_lds(KernelT kern, size_t lds) {
 
 // Launch geometry of upsample_loss_kernel, from the exact index rule (same float ops as the device).
 struct LossGeom {
-    int xsplit, rows_max, emax, xw_max, threads;
+    int xsplit, rows_max, emax, xw_max, threads, ncmax;
     size_t lds;
 };
 
@@ -127,6 +127,7 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         lds = (lds + 15) & ~(size_t)15;
         if (lds <= 64 * 1024 || (cw == 1 && lds <= 150 * 1024)) {
             g->xsplit = xsplit; g->rows_max = rows_max; g->emax = emax; g->xw_max = xw_max; g->threads = UL_T;
+            g->ncmax = ncmax;
             g->lds = lds;
             found = true;
             break;
@@ -156,12 +157,21 @@ static int launch_loss(int mode, bool grad, const float* logits, const int64_t* 
         if (rc) return rc;                                                                                   \
         hipLaunchKernelGGL((upsample_loss_kernel<M, G>), grid, block, g.lds, st, a);                         \
     }
+#define UL_GO3(M, G, NC)                                                                                     \
+    {                                                                                                        \
+        int rc = set_lds(upsample_loss_kernel<M, G, NC>, g.lds);                                             \
+        if (rc) return rc;                                                                                   \
+        hipLaunchKernelGGL((upsample_loss_kernel<M, G, NC>), grid, block, g.lds, st, a);                     \
+    }
     if (mode == 0) {
-        if (grad) UL_GO(0, true) else UL_GO(0, false)
+        if (grad) {
+            if (g.ncmax == 16) UL_GO3(0, true, 16) else UL_GO(0, true)
+        } else UL_GO(0, false)
     } else {
         UL_GO(1, false)
     }
 #undef UL_GO
+#undef UL_GO3
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -184,7 +194,11 @@ int denet_loss_pair_fwd(const float* logits, const int64_t* Yq_full, const float
                 g1.xw_max, alpha, gamma, part_p, nullptr, nullptr};
     dim3 grid((unsigned)(nb0 > nb1 ? nb0 : nb1), (unsigned)(N + NB)), block(UL_T);
     hipStream_t st = (hipStream_t)stream;
-    if (grad) {
+    if (grad && g0.ncmax == 16) {
+        int rc = set_lds(upsample_loss_pair_kernel<true, 16>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 16>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
+    } else if (grad) {
         int rc = set_lds(upsample_loss_pair_kernel<true>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(upsample_loss_pair_kernel<true>, grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
