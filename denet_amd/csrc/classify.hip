@@ -61,8 +61,9 @@ struct WnBuild {
     float* Wn_out /*[N][K][C]*/;
 };
 
-template <typename T, int RT, int NLD, bool BUILD>
-__global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
+// NW waves per block split the channels: NLD = C / (2 NW) k-steps per wave.
+template <typename T, int RT, int NLD, bool BUILD, int NW>
+__global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
                                                           int64_t wn_stride, const int64_t* __restrict__ labels,
                                                           int way, int K, int C, int P, int base,
                                                           float* __restrict__ logits, float* __restrict__ bin,
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     const int j = lane & 31, hh = lane >> 5;
     const int ldw = C + 1;
 
-    const int cper = C >> 2;                       // channels per wave: 16, 32, 64 or 128
+    constexpr int NT = 64 * NW;
+    const int cper = C / NW;                       // channels per wave
     const int cbeg = wave * cper;
     const int pa = p0 + 2 * j;
     const bool fast = (p0 + CL_TP <= P);           // block-uniform: only the last tile of an episode is partial
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
 
     // the rows this episode's ways overwrite: thread group jw = tid / 64 sums the partials of way jw
     // (16-byte column pieces, all loads in flight together, fixed order)
-    constexpr int NSL = NLD / 2;                   // C / 16
+    constexpr int NSL = NLD * NW / 8;              // C / 16
     f32x4 pv = {0.f, 0.f, 0.f, 0.f};
     int prow = -1;
     if constexpr (BUILD) {
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         const int64_t* lab = labels + (int64_t)n * way;
         const int nv = (K * C) >> 2;
 #pragma unroll 1
-        for (int base = 0; base < nv; base += 256 * 8) {
+        for (int base = 0; base < nv; base += NT * 8) {
             f32x4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i4 = base + u * 256 + tid;
+                const int i4 = base + u * NT + tid;
 #ifdef DENET_DIAG_NO_WN
                 v[u] = f32x4{1.f, 2.f, 3.f, 4.f};
 #else
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
                 f32x4 m[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int i4 = base + u * 256 + tid;
+                    const int i4 = base + u * NT + tid;
                     m[u] = *reinterpret_cast<const f32x4*>(msk + (int64_t)min(i4, nv - 1) * 4);
                 }
 #pragma unroll
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i4 = base + u * 256 + tid;
+                const int i4 = base + u * NT + tid;
                 if (i4 < nv) {
                     const int idx = i4 * 4;
                     const int k = idx / C, c = idx - k * C;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
             float* d = sm + prow;
             d[0] = pv[0]; d[1] = pv[1]; d[2] = pv[2]; d[3] = pv[3];
         }
-        // more than 4 ways: the remaining ones, four at a time (winners own distinct rows)
-        for (int jw0 = 4; jw0 < way; jw0 += 4) {
+        // more than NW ways: the remaining ones, NW at a time (winners own distinct rows)
+        for (int jw0 = NW; jw0 < way; jw0 += NW) {
             const int jw = jw0 + (tid >> 6), c4 = tid & 63;
             if (jw < way && c4 < (C >> 2)) {
                 const int64_t* lab = labels + (int64_t)n * way;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         // Wn[n] for the backward pass: tile t writes rows t, t + tiles, ... (one 1 KB row = one store per thread)
         float* dst = wb.Wn_out + (int64_t)n * K * C;
         for (int k = blockIdx.x; k < K; k += gridDim.x)
-            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
+            for (int c = tid; c < C; c += NT) dst[k * C + c] = sm[k * ldw + c];
     }
 
     f32x16 acc[RT][2];
@@ -255,9 +257,10 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
         const int col = tid & 63, rg = tid >> 6;
         const int p = p0 + col;
         const int ws = K * CL_LD;
-        for (int k = rg; k < K; k += 4) {
+        for (int k = rg; k < K; k += NW) {
             const int o = k * CL_LD + col;
-            const float v = ((sm[o] + sm[ws + o]) + sm[2 * ws + o]) + sm[3 * ws + o];
+            float v = ((sm[o] + sm[ws + o]) + sm[2 * ws + o]) + sm[3 * ws + o];
+            if constexpr (NW == 8) v += ((sm[4 * ws + o] + sm[5 * ws + o]) + sm[6 * ws + o]) + sm[7 * ws + o];
             sm[o] = v;
             if (p < P) logits[((int64_t)n * K + k) * P + p] = v;
         }
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void classify_fwd_kernel(const T* __restrict__
     if (bin == nullptr) return;
     __syncthreads();
     // binary logits: ch1 = row label, ch0 = max over the other rows (utils/operations.py:327-337)
-    for (int item = tid; item < way * CL_TP; item += 256) {
+    for (int item = tid; item < way * CL_TP; item += NT) {
         const int jw = item >> 6, col = item & 63;
         const int p = p0 + col;
         if (p >= P) continue;
@@ -338,28 +341,28 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                                int64_t way, int64_t K, int64_t C, int64_t P, int base, float* logits, float* bin,
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
-    const size_t a = (size_t)K * (C + 1), b = (size_t)4 * K * CL_LD;
+    // K <= 32: eight waves per block (32 MFMA k-steps per wave instead of 64; there is one block per CU
+    // at batch 8, so the extra waves are free); larger K keeps four (the partial tiles must fit in LDS)
+    const int NW = RT == 1 ? 8 : 4;
+    const size_t a = (size_t)K * (C + 1), b = (size_t)NW * K * CL_LD;
     const size_t lds = (a > b ? a : b) * 4;
     if (lds > 160 * 1024) return DENET_E_UNSUPPORTED;
-    dim3 grid((unsigned)((P + CL_TP - 1) / CL_TP), (unsigned)N), block(256);
-#define CL_FWD2(R, L)                                                                                       \
+    dim3 grid((unsigned)((P + CL_TP - 1) / CL_TP), (unsigned)N), block((unsigned)(64 * NW));
+#define CL_FWD3(R, L, W)                                                                                    \
     {                                                                                                       \
-        int rc = set_lds(classify_fwd_kernel<T, R, L, BUILD>, lds);                                         \
+        int rc = set_lds(classify_fwd_kernel<T, R, L, BUILD, W>, lds);                                      \
         if (rc) return rc;                                                                                  \
-        hipLaunchKernelGGL((classify_fwd_kernel<T, R, L, BUILD>), grid, block, lds, st, Fq, Wn, wn_stride,  \
+        hipLaunchKernelGGL((classify_fwd_kernel<T, R, L, BUILD, W>), grid, block, lds, st, Fq, Wn, wn_stride, \
                            labels, (int)way, (int)K, (int)C, (int)P, base, logits, bin, wb);                \
     }
-#define CL_FWD(R)                       \
-    if (C == 64) CL_FWD2(R, 8) else CL_FWD2(R, 32)
     switch (RT) {
-        case 1: CL_FWD(1); break;
-        case 2: CL_FWD(2); break;
-        case 3: CL_FWD(3); break;
-        case 4: CL_FWD(4); break;
+        case 1: if (C == 64) CL_FWD3(1, 4, 8) else CL_FWD3(1, 16, 8) break;
+        case 2: if (C == 64) CL_FWD3(2, 8, 4) else CL_FWD3(2, 32, 4) break;
+        case 3: if (C == 64) CL_FWD3(3, 8, 4) else CL_FWD3(3, 32, 4) break;
+        case 4: if (C == 64) CL_FWD3(4, 8, 4) else CL_FWD3(4, 32, 4) break;
         default: return DENET_E_UNSUPPORTED;
     }
-#undef CL_FWD2
-#undef CL_FWD
+#undef CL_FWD3
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -425,7 +428,12 @@ static int launch_classify_bwd(const T* Fq, const float* Wn, const float* da, co
     dim3 grid((unsigned)n_part, (unsigned)N), block(256);
     ClsBwdArgs g{Fq, Wn, da, db, scale, gmul, nullptr, 0, (int)N, (int)K, (int)C, (int)P, n_part, dFq, dWn_part,
                  nullptr};
-#define CL_BWD(R) hipLaunchKernelGGL((classify_bwd_kernel<T, R>), grid, block, lds, st, g)
+#define CL_BWD(R)                                                              \
+    {                                                                          \
+        int rc = set_lds(classify_bwd_kernel<T, R>, lds);                      \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((classify_bwd_kernel<T, R>), grid, block, lds, st, g); \
+    }
     switch (RT) {
         case 1: CL_BWD(1); break;
         case 2: CL_BWD(2); break;

@@ -16,7 +16,11 @@ typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
 //   dFq[c][p]  = sum_k Wn[k][c] * dL[k][p]                        (A = Wn^T from L2, B = dL from LDS)
 //   dWn_part[tile][k][c] = sum_{p in tile} dL[k][p] * Fq[c][p]    (A = dL from LDS, B = Fq^T: each
 //        lane holds 32 consecutive positions of one channel row in registers; the MFMA k index of
-//        step s is position 32*(lane>>5) + s for both operands)
+//        step s is position 32*(lane>>5) + s for both operands).  The MFMA wants lane <-> channel,
+//        memory wants lane <-> position: the [32 channels x 64 positions] tile is therefore loaded
+//        with lanes along the positions (a wave load = four 256-byte row pieces; lane <-> channel
+//        loads touch 64 cache lines per instruction and re-fetch every line eight times through the
+//        16 KB L1) and turned through a wave-private LDS tile.
 // The partial dWn slabs are summed by K2b (no float atomics: deterministic).
 // scale[n] comes from `scale`, or, when part_k != nullptr, is derived here from the loss kernel's
 // per-block partial sums exactly as loss_finalize does (and written to `scale_out` by tile 0), which
@@ -29,7 +33,10 @@ struct ClsBwdArgs {
     void* dFq;
     float *dWn_part, *scale_out;
 };
-#define CLS_BWD_LDS(K) ((size_t)(((K) + 1) & ~1) * CL_LD * 4)
+#define CL_TS 68          // LDS row stride of a wave's transposition tile (16-byte rows, conflict-free b128)
+#define CLS_BWD_DL(K) ((((K) + 1) & ~1) * CL_LD)                       // floats: dL [KP][CL_LD]
+#define CLS_BWD_LDS_NW(K, NW) ((size_t)(CLS_BWD_DL(K) + (NW) * 32 * CL_TS) * 4)
+#define CLS_BWD_LDS(K) CLS_BWD_LDS_NW(K, 4)
 
 // 1/(N * sum of the episode's den partials): every lane of the calling wave gets the value
 __device__ __forceinline__ float episode_den(const float* __restrict__ part_k, int parts_k, int n) {
@@ -61,7 +68,7 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
     // requested before the first wait: the block then pays one memory latency, not five.
     constexpr bool PRE = (RT == 1);
     float av[TPW][PRE ? NA : 1];
-    float fv[TPW][PRE ? 32 : 1];
+    f32x4 fraw[PRE ? TPW : 1][8];
 
     auto load_av = [&](int ct, float* dst) {
 #pragma unroll
@@ -71,31 +78,41 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
             dst[u] = kk < K ? v : 0.f;
         }
     };
-    auto load_fv = [&](int ct, float* dst) {
-        const int pb = p0 + 32 * hh;
-        const T* src = Fq + ((int64_t)n * C + ct * 32 + j) * P + pb;
-        if (fast) {
-            if constexpr (sizeof(T) == 4) {
+    // raw tile of this wave: lane = (row r4 = lane>>4 of a group of 4 channels, 4 positions 4*(lane&15)..)
+    const int r4 = lane >> 4, c16 = lane & 15;
+    auto load_raw = [&](int ct, f32x4 (&raw)[8]) {
+        const int pb = p0 + 4 * c16;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)src + 4 * m);
-                    dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
+        for (int i = 0; i < 8; ++i) {
+            const T* rowp = Fq + ((int64_t)n * C + ct * 32 + 4 * i + r4) * P;
+            if (fast) {
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)rowp + pb);
+                    raw[i] = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    const u16x2_u v0 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb);
+                    const u16x2_u v1 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb + 2);
+                    raw[i] = f32x4{bf16_to_f32(v0[0]), bf16_to_f32(v0[1]), bf16_to_f32(v1[0]), bf16_to_f32(v1[1])};
                 }
             } else {
+                // partial last tile: clamped unconditional loads, zeroed by a select (no load inside a branch)
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    const u16x2_u v = *reinterpret_cast<const u16x2_u*>((const unsigned short*)src + 2 * m);
-                    dst[2 * m] = bf16_to_f32(v[0]); dst[2 * m + 1] = bf16_to_f32(v[1]);
+                for (int e = 0; e < 4; ++e) {
+                    const float v = FeatIO<T>::load(rowp + min(pb + e, P - 1));
+                    raw[i][e] = (pb + e < P) ? v : 0.f;
                 }
             }
-        } else {
-            // partial last tile: clamped unconditional loads, zeroed by a select (no load inside a branch)
-            const T* rowp = Fq + ((int64_t)n * C + ct * 32 + j) * P;
+        }
+    };
+    float* tsm = sm + CLS_BWD_DL(K) + wave * 32 * CL_TS;     // this wave's transposition tile [32][CL_TS]
+    auto turn = [&](const f32x4 (&raw)[8], float* dst) {
+        // same wave writes and reads: LDS operations of a wave complete in order
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float v = FeatIO<T>::load(rowp + min(pb + s, P - 1));
-                dst[s] = (pb + s < P) ? v : 0.f;
-            }
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(tsm + (4 * i + r4) * CL_TS + 4 * c16) = raw[i];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tsm + j * CL_TS + 32 * hh + 4 * m);
+            dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
         }
     };
     if constexpr (PRE) {
@@ -104,7 +121,7 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
             const int ct = wave + NW * i;
             if (ct < nct) {
                 if (dFq != nullptr) load_av(ct, av[i]);
-                if (dWn_part != nullptr) load_fv(ct, fv[i]);
+                if (dWn_part != nullptr) load_raw(ct, fraw[i]);
             }
         }
     }
@@ -167,8 +184,16 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
             for (int e = 0; e < 16; ++e) {
                 const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 T* dst = dFq + ((int64_t)n * C + c) * P + pa;
-                if (pa < P) FeatIO<T>::store(dst, a0[e]);
-                if (pa + 1 < P) FeatIO<T>::store(dst + 1, a1[e]);
+                if (pa + 1 < P) {
+                    // two adjacent positions in one store: a wave store is two contiguous 256-byte row pieces
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{a0[e], a1[e]};
+                    } else {
+                        *reinterpret_cast<u16x2_u*>(dst) = u16x2_u{f32_to_bf16(a0[e]), f32_to_bf16(a1[e])};
+                    }
+                } else if (pa < P) {
+                    FeatIO<T>::store(dst, a0[e]);
+                }
             }
         }
     }
@@ -181,7 +206,13 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
             if (ct >= nct) continue;
             const int c0 = ct * 32;
             float fvl[32];
-            if constexpr (!PRE) load_fv(ct, fvl);
+            if constexpr (PRE) {
+                turn(fraw[i], fvl);
+            } else {
+                f32x4 raw[8];
+                load_raw(ct, raw);
+                turn(raw, fvl);
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const int row = 32 * rt + j;
@@ -194,7 +225,7 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
                 for (int s = 0; s < 32; ++s) {
                     float a = arow[s];
                     a = ok ? a : 0.f;
-                    const float bq = PRE ? fv[i][PRE ? s : 0] : fvl[s];
+                    const float bq = fvl[s];
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
                 }
 #pragma unroll

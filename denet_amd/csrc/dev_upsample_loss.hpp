@@ -353,12 +353,13 @@ __device__ __forceinline__ void loss_finalize_body(const float* __restrict__ par
                                                    const float* __restrict__ part_p, int N, int NB, int parts_k,
                                                    int parts_p, int pooled, float* __restrict__ out,
                                                    float* __restrict__ per_episode, float* __restrict__ scale,
-                                                   float* red /*LDS, 4 floats*/) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                   float* red /*LDS, 8 floats*/) {
+    // any block size that is a multiple of 64, up to 512
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nwv = nt >> 6;
     if (part_k && !pooled) {
         // trainer/utils.py:270-277: mean over episodes of per-episode weighted means
         float ls = 0.f;
-        for (int n = wave; n < N; n += 4) {
+        for (int n = wave; n < N; n += nwv) {
             float nu = 0.f, de = 0.f;
             for (int y = lane; y < parts_k; y += 64) {
                 nu += part_k[((int64_t)n * parts_k + y) * 2];
@@ -373,32 +374,32 @@ __device__ __forceinline__ void loss_finalize_body(const float* __restrict__ par
                 ls += l;
             }
         }
-        ls = block_sum_256(ls, red);
+        ls = block_sum(ls, red);
         if (tid == 0) out[0] = ls / (float)N;
     }
     if (part_k && pooled) {
         // loss/losses.py:39-44 on a batch: one weighted mean over every pixel of every sample
         float nu = 0.f, de = 0.f;
-        for (int i = tid; i < N * parts_k; i += 256) {
+        for (int i = tid; i < N * parts_k; i += nt) {
             nu += part_k[(int64_t)i * 2];
             de += part_k[(int64_t)i * 2 + 1];
         }
-        nu = block_sum_256(nu, red);
-        de = block_sum_256(de, red);
+        nu = block_sum(nu, red);
+        de = block_sum(de, red);
         if (tid == 0) out[0] = nu / de;
         if (scale)
-            for (int n = tid; n < N; n += 256) scale[n] = 1.f / de;
+            for (int n = tid; n < N; n += nt) scale[n] = 1.f / de;
         if (per_episode)
-            for (int n = tid; n < N; n += 256) per_episode[n] = nu / de;
+            for (int n = tid; n < N; n += nt) per_episode[n] = nu / de;
     }
     if (part_p) {
         float nu = 0.f, de = 0.f;
-        for (int i = tid; i < NB * parts_p; i += 256) {
+        for (int i = tid; i < NB * parts_p; i += nt) {
             nu += part_p[(int64_t)i * 2];
             de += part_p[(int64_t)i * 2 + 1];
         }
-        nu = block_sum_256(nu, red);
-        de = block_sum_256(de, red);
+        nu = block_sum(nu, red);
+        de = block_sum(de, red);
         if (tid == 0) out[1] = nu / de;
     }
 }
@@ -408,7 +409,7 @@ static __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* 
                                                            int parts_k, int parts_p, int pooled,
                                                            float* __restrict__ out, float* __restrict__ per_episode,
                                                            float* __restrict__ scale) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     loss_finalize_body(part_k, part_p, N, NB, parts_k, parts_p, pooled, out, per_episode, scale, red);
 }
 

@@ -58,19 +58,20 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
 //   B2  sliced chain, middle: dproto -> dpool -> dz -> split-K partials of W2^T dz     (tiny)
 //   B3  K2b parameter gradients   ||  coef + dFs = mask * coef (K1b)
 // ---------------------------------------------------------------------------
+#define B1_NW 8           // waves per block of the first backward launch (one 32-channel tile per wave)
 template <typename T, int RT>
-__global__ __launch_bounds__(256) void head_bwd_dwn_kernel(ClsBwdArgs g, ClsBwdArgs g2, const float* __restrict__ part_p,
+__global__ __launch_bounds__(64 * B1_NW) void head_bwd_dwn_kernel(ClsBwdArgs g, ClsBwdArgs g2, const float* __restrict__ part_p,
                                                           int NB, int parts_p, float* __restrict__ losses) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n_part = g.n_part;
     if ((int)blockIdx.x < n_part) {
-        classify_bwd_body<T, RT, 4>(g, blockIdx.y, blockIdx.x, sm);
+        classify_bwd_body<T, RT, B1_NW>(g, blockIdx.y, blockIdx.x, sm);
         if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
             __syncthreads();
             loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
         }
     } else {
-        classify_bwd_body<T, RT, 4>(g2, blockIdx.y, blockIdx.x - n_part, sm);
+        classify_bwd_body<T, RT, B1_NW>(g2, blockIdx.y, blockIdx.x - n_part, sm);
     }
 }
 
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, hipStream_t st) {
-    hipLaunchKernelGGL((head_bwd_dwn_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N), dim3(256),
-                       CLS_BWD_LDS(g.K), st, g, g2, part_p, NB, parts_p, losses);
+    const size_t lds = CLS_BWD_LDS_NW(g.K, B1_NW);
+    if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_kernel<T, RT>), lds)) return DENET_E_LAUNCH;
+    hipLaunchKernelGGL((head_bwd_dwn_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N), dim3(64 * B1_NW), lds,
+                       st, g, g2, part_p, NB, parts_p, losses);
     return DENET_OK;
 }
 
