@@ -55,8 +55,8 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
 // (5-30 us for a few MB), so the step time is the LENGTH of the dependency chain; independent
 // pieces therefore share a launch, block roles picked by blockIdx:
 //   B1  dWn slabs (K3b, first half)  ||  dFq (K3b, second half)   [+ the loss reduction, in block (0,0)]
-//   B2  sliced chain, middle: dproto -> dpool -> dz -> split-K partials of W2^T dz     (tiny)
-//   B3  K2b parameter gradients   ||  coef + dFs = mask * coef (K1b)
+//   B2  sliced chain, middle: dproto -> dpool -> dz -> split-K partials of W2^T dz  ||  dweight
+//   B3  dW1, dW2, dWl and the bias gradients  ||  coef + dFs = mask * coef (K1b)
 // ---------------------------------------------------------------------------
 #define B1_NW 8           // waves per block of the first backward launch (one 32-channel tile per wave)
 template <typename T, int RT>
@@ -76,17 +76,20 @@ __global__ __launch_bounds__(64 * B1_NW) void head_bwd_dwn_kernel(ClsBwdArgs g, 
 }
 
 template <int CJ, int NS>
-__global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a) {
+__global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a, PeParamsArgs pa, int nchain) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NSL = 64 * CJ / SC_SL;
-    chain_mid_bwd_body<CJ, NS>(a, blockIdx.x / NSL, blockIdx.x % NSL, sm);
+    if ((int)blockIdx.x < nchain)
+        chain_mid_bwd_body<CJ, NS>(a, blockIdx.x / NSL, blockIdx.x % NSL, sm);
+    else
+        proto_extend_bwd_params_body(pa, 3, blockIdx.x - nchain, sm);     // dweight: needs only B1's slabs
 }
 
 template <typename T, int NSLT>
 __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, CoefArgs ca, const float* __restrict__ mask,
                                                            T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bx = blockIdx.x, nms = gridDim.x - 4 * gx;
+    const int bx = blockIdx.x, nms = gridDim.x - 3 * gx;
     if (bx < nms) {
         masked_sum_bwd_body<T, NSLT>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
     } else {
@@ -105,10 +108,11 @@ static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float
     return DENET_OK;
 }
 
-static int launch_bwd_mid(const ChainMidArgs& a, int groups, int C, int shot, hipStream_t st) {
-    const int nsl = C / SC_SL;
-    dim3 grid((unsigned)(groups * nsl)), block(SC_THREADS);
-#define CM_GO(CJ, NS) hipLaunchKernelGGL((head_bwd_mid_kernel<CJ, NS>), grid, block, SC_CM_LDS, st, a)
+static int launch_bwd_mid(const ChainMidArgs& a, const PeParamsArgs& pa, int groups, int C, int shot, hipStream_t st) {
+    const int nsl = C / SC_SL, nchain = groups * nsl;
+    dim3 grid((unsigned)(nchain + pa.K * (C >> 4))), block(SC_THREADS);
+    const size_t lds = SC_CM_LDS > 4096 ? SC_CM_LDS : 4096;
+#define CM_GO(CJ, NS) hipLaunchKernelGGL((head_bwd_mid_kernel<CJ, NS>), grid, block, lds, st, a, pa, nchain)
 #define CM_NS(CJ)                     \
     if (shot == 1) CM_GO(CJ, 1);      \
     else if (shot <= 3) CM_GO(CJ, 3); \
@@ -276,27 +280,27 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
-    // B2: sliced chain, middle
+    PeParamsArgs pa{nullptr, s.u2, s.u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N, (int)way,
+                    (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part};
+    // B2: sliced chain, middle || dweight
     {
         ChainMidArgs cm{s.dWn_part, s.S, s.cnt, s.gate, gate_mask, Wl, W2, labels, n_part, (int)way, (int)shot,
                         (int)K, s.u2, s.u3, s.dpool, s.dh_part};
         const bool on = probe && probe->which == DENET_K_PE_BWD_CHAIN && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        int rc = launch_bwd_mid(cm, (int)NB, (int)C, (int)shot, st);
+        int rc = launch_bwd_mid(cm, pa, (int)NB, (int)C, (int)shot, st);
         if (rc) return rc;
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
     // B3: parameter gradients || coef + dFs
     {
-        PeParamsArgs pa{nullptr, s.u2, s.u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N,
-                        (int)way, (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part};
         CoefArgs ca{s.dh_part, s.hidden, W1, s.dpool, s.gate, s.cnt, (int)shot, (int)(C / 16), (float)P, SC_EPS};
-        const int gx = pe_params_gx((int)K, (int)C);
+        const int gx = (int)C / WG_ROWS;              // blocks of each of the roles dW1, dW2, dWl
         const int rpb = 16, ncb = (int)(C / 16);
         size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;
         if (lds < 4096) lds = 4096;
-        dim3 grid((unsigned)(4 * gx + B * ncb)), block(256);
+        dim3 grid((unsigned)(3 * gx + B * ncb)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
 #define TAIL_GO(TT, NSLT)                                                                                     \

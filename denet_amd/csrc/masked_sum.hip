@@ -52,7 +52,10 @@ extern "C" int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_
     return DENET_OK;
 }
 
-static inline int pick_rows_per_block(int64_t C) { return C >= 16 ? 16 : (int)C; }
+#ifndef DENET_RPB
+#define DENET_RPB 16
+#endif
+static inline int pick_rows_per_block(int64_t C) { return C >= DENET_RPB ? DENET_RPB : (int)C; }
 
 extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float* mask, int64_t B, int64_t C,
                                     int64_t P, float* S, void* stream) {
