@@ -9,8 +9,9 @@ resident in HBM: K0..K5 forward, both losses, and the backward of loss_k down
 to dFq, dFs and the seven estimator parameter gradients (SURVEY.md §8d
 "boundary being timed").  Feature producer and optimizer are excluded, as in
 the metric's definition.  With N > 1 each rank owns its own batch (episodes are
-independent: weak scaling) and the step ends with ONE RCCL all-reduce (AVG) of
-the flat parameter-gradient bucket.
+independent: weak scaling) and the step contains ONE RCCL all-reduce (AVG) of
+the flat parameter-gradient bucket, started as soon as the bucket is complete
+and overlapped with the last kernel's dFs stream.
 
 Rank 0 prints one JSON line.  `roofline` is for the dominant kernel, timed with
 HIP events on the launch stream inside the timed region; `cpu_baseline` is the
@@ -109,13 +110,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # one rank per GPU; the modulo only matters for a dry run of the N > 1 path on a one-GPU box
+    # (DENET_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DENET_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    # gloo (dry runs only) has no AVG: it sums, which is the same exchange
+    reduce_op = None if dist is None else (dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
 
     shape = CONFIGS[args.config]
     if args.episodes > 0:
@@ -134,14 +144,26 @@ def main():
     def step():
         eng.forward(ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params, with_grad=True,
                     defer_losses=True)
-        eng.backward(ep["Fq"], labels, params)
-        if world > 1:
-            dist.all_reduce(eng.grad_bucket, op=dist.ReduceOp.AVG)
+        if world == 1:
+            eng.backward(ep["Fq"], labels, params)
+        else:
+            # every gradient except dFs, then the bucket's all-reduce on RCCL's stream while the 70 MB
+            # dFs stream (which nothing in the step reads) runs on ours; the step ends when both have
+            eng.backward(ep["Fq"], labels, params, phase=1)
+            work = dist.all_reduce(eng.grad_bucket, op=reduce_op, async_op=True)
+            eng.backward(ep["Fq"], labels, params, phase=2)
+            work.wait()
 
+    dbg = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("DENET_BENCH_DEBUG") else (lambda m: None)
+    if os.environ.get("DENET_BENCH_DEBUG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(30, exit=True)       # a hung rank prints its stack
+    dbg("engine ready")
     # ---- warm-up (also loads code objects, sets LDS attributes) ----
     for _ in range(max(args.warmup, 2)):
         step()
     torch.cuda.synchronize()
+    dbg("warm-up done")
 
     # ---- per-kernel breakdown (untimed): HIP events around each kernel in turn ----
     kb = kernel_bytes(shape, sF)
@@ -159,6 +181,7 @@ def main():
                 ts.append(e0.elapsed_ms(e1) * 1e3)
             breakdown[name] = statistics.median(ts)
         eng.set_probe(None, None, None)
+    dbg("breakdown done")
     probe = args.probe
     if probe == "auto":
         probe = max(breakdown, key=breakdown.get)
@@ -200,6 +223,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     eng.set_probe(None, None, None)
+    dbg("timed region done")
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -264,7 +288,13 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        # Every collective of the run is behind us (the MAX of the elapsed times was the last one).
+        # Leave without tearing the process group down: on dry runs of this path (gloo, two ranks on
+        # one GPU) destroy_process_group, and a final barrier, were seen to hang after the result
+        # line had been printed; there is nothing left to clean up.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DENET_HIP_LIB") or os.path.join(_HERE, "libdenet_hip.so")
 
 F32, BF16 = 0, 1
+BWD_HAVE_FOCAL, BWD_NO_DFS, BWD_ONLY_DFS = 1, 2, 4      # denet_head_step_bwd flags (include/denet_hip.h)
 
 # signature table: p = device pointer (tensor / None), l = int64, i = int, f = float,
 # h = host pointer (ctypes object / None)

@@ -242,10 +242,13 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
                                    int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                                    int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
                                    float* db2, float* dWl, float* dbl, float* losses /*NULL unless deferred*/,
-                                   int have_focal, void* ws, int64_t ws_bytes, const denet_probe_t* probe,
+                                   int flags, void* ws, int64_t ws_bytes, const denet_probe_t* probe,
                                    void* stream) {
     if (!ws || !dFq || !dFs || !Fq) return DENET_E_BADARG;
     if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return DENET_E_BADARG;
+    const bool have_focal = (flags & DENET_BWD_HAVE_FOCAL) != 0;
+    const bool no_dfs = (flags & DENET_BWD_NO_DFS) != 0, only_dfs = (flags & DENET_BWD_ONLY_DFS) != 0;
+    if (no_dfs && only_dfs) return DENET_E_BADARG;
     if (!dW1 || !db1 || !dW2 || !db2 || !dWl || !dbl || !dweight || !labels || !W1 || !W2 || !Wl)
         return DENET_E_BADARG;
     if (!(C == 64 || C == 256) || K > 128 || shot > 8 || N > 65535) return DENET_E_UNSUPPORTED;
@@ -261,10 +264,10 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     const bool f32 = feat_dtype == DENET_F32;
     hipStream_t st = (hipStream_t)stream;
 
-    // B1: dWn slabs || dFq; scale[n] is derived from the loss partials inside the kernel
     ClsBwdArgs g{Fq, s.Wn, s.dlog_a, s.dlog_b, nullptr, grad_loss_k, s.part_k, (int)pk, (int)N, (int)K, (int)C,
                  (int)P, n_part, nullptr, s.dWn_part, s.scale};
-    {
+    // B1: dWn slabs || dFq; scale[n] is derived from the loss partials inside the kernel
+    if (!only_dfs) {
         ClsBwdArgs g2 = g;
         g2.dFq = dFq;
         g2.dWn_part = nullptr;
@@ -283,7 +286,7 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     PeParamsArgs pa{nullptr, s.u2, s.u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N, (int)way,
                     (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part};
     // B2: sliced chain, middle || dweight
-    {
+    if (!only_dfs) {
         ChainMidArgs cm{s.dWn_part, s.S, s.cnt, s.gate, gate_mask, Wl, W2, labels, n_part, (int)way, (int)shot,
                         (int)K, s.u2, s.u3, s.dpool, s.dh_part};
         const bool on = probe && probe->which == DENET_K_PE_BWD_CHAIN && probe->start && probe->stop;
@@ -296,11 +299,14 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     // B3: parameter gradients || coef + dFs
     {
         CoefArgs ca{s.dh_part, s.hidden, W1, s.dpool, s.gate, s.cnt, (int)shot, (int)(C / 16), (float)P, SC_EPS};
-        const int gx = (int)C / WG_ROWS;              // blocks of each of the roles dW1, dW2, dWl
+        // one launch, or its two halves apart (DENET_BWD_NO_DFS / DENET_BWD_ONLY_DFS): the kernel takes
+        // its first gridDim.x - 3*gx blocks as dFs blocks
+        const int gx = only_dfs ? 0 : (int)C / WG_ROWS;      // blocks of each of the roles dW1, dW2, dWl
         const int rpb = 16, ncb = (int)(C / 16);
+        const int64_t ndfs = no_dfs ? 0 : B * ncb;
         size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;
         if (lds < 4096) lds = 4096;
-        dim3 grid((unsigned)(3 * gx + B * ncb)), block(256);
+        dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
 #define TAIL_GO(TT, NSLT)                                                                                     \

@@ -69,12 +69,16 @@ class HeadStepEngine:
              N, way, shot, K, C, h, w, H, W, mode, self.logits_full, self.logits_binary,
              self.losses, self.ws, self.ws_bytes, self._probe)
 
-    def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None):
+    def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None, phase=0):
+        """phase 0: the whole backward.  phase 1: every gradient except dFs (the parameter-gradient
+        bucket is complete afterwards); phase 2: dFs.  Data-parallel callers start the bucket's
+        all-reduce between phases 1 and 2 so that it overlaps with the dFs stream."""
         N, way, shot, K, C, h, w, H, W = self.dims
         g = self.grads
+        flags = (_lib.BWD_HAVE_FOCAL if self._have_focal else 0) | {0: 0, 1: _lib.BWD_NO_DFS, 2: _lib.BWD_ONLY_DFS}[phase]
         call("denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
              params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
              N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
              g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
-             g["map.linear.bias"], self.losses if self._deferred else None, 1 if self._have_focal else 0,
+             g["map.linear.bias"], self.losses if self._deferred else None, flags,
              self.ws, self.ws_bytes, self._probe)

@@ -211,8 +211,11 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
  * Everything DENetTrainer.step does between the feature producer and
  * optimizer.step() (trainer/trainers.py:951-975; wrappers trainer/utils.py:
  * 251-303): K0..K5 forward (+ the loss gradient slabs when with_grad), then
- * K3b, K2b, K1b, as three launches whose independent halves run side by side (B1: dWn slabs;
- * B2: K2b chain || dFq; B3: parameter gradients || dFs).  with_grad = DENET_GRAD_DEFER_LOSSES
+ * K3b, K2b, K1b, as three launches whose independent halves run side by side (B1: dWn slabs ||
+ * dFq; B2: middle of the sliced K2b chain || dweight; B3: dW1, dW2, dWl, biases || coef + dFs).
+ * The gate / projection mat-vecs of K2 and K2b are cut into 16-row slices that run on different
+ * CUs; the exchanges between them are the launch boundaries (csrc/dev_chain_sliced.hpp).
+ * with_grad = DENET_GRAD_DEFER_LOSSES
  * moves the reduction of the loss partials into B1 (losses[] is then valid after the backward
  * call, and the forward needs Yq_full).  ws: denet_head_step_workspace(...) bytes, 256-B aligned,
  * shared by the two calls of one step.  Yq / Yq_full may be NULL (test mode:
@@ -231,9 +234,16 @@ int denet_binary_iou_counts_fused(const float* logits2 /*[N,2,h,w]*/, const int6
 #define DENET_K_WCE_FWD          5   /* K4 (+K5 in the same launch when both label maps are given) */
 #define DENET_K_FOCAL_FWD        6   /* K5 alone (no Yq_full)                                      */
 #define DENET_K_LOSS_FINALIZE    7
-#define DENET_K_CLASSIFY_BWD     8   /* B1: dWn slabs (+ deferred loss reduction)                  */
-#define DENET_K_PE_BWD_CHAIN     9   /* B2: K2b chain of transposed mat-vecs || dFq             */
-#define DENET_K_MASKED_SUM_BWD   10  /* B3: K2b parameter gradients || dFs = mask*coef          */
+#define DENET_K_CLASSIFY_BWD     8   /* B1: dWn slabs || dFq (+ deferred loss reduction)           */
+#define DENET_K_PE_BWD_CHAIN     9   /* B2: sliced K2b chain, middle || dweight                    */
+#define DENET_K_MASKED_SUM_BWD   10  /* B3: dW1, dW2, dWl, biases || coef + dFs = mask*coef        */
+/* denet_head_step_bwd flags.  The dFs blocks are the last consumer of the step and nothing reads
+ * their output, so a data-parallel caller may run the backward in two calls and start the
+ * all-reduce of the parameter gradients between them (it then overlaps with the 70 MB dFs stream):
+ * first NO_DFS (every gradient except dFs), then ONLY_DFS with the same arguments. */
+#define DENET_BWD_HAVE_FOCAL     1   /* the forward was given Yq                                   */
+#define DENET_BWD_NO_DFS         2   /* everything except the dFs blocks                           */
+#define DENET_BWD_ONLY_DFS       4   /* only the dFs blocks (after a NO_DFS call of the same step)  */
 typedef struct denet_probe {
     int32_t which;      /* DENET_K_* */
     int32_t reserved;
@@ -259,7 +269,7 @@ int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
                         int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
                         float* db2, float* dWl, float* dbl,
                         float* losses /* [2]; NULL unless the forward ran with DENET_GRAD_DEFER_LOSSES */,
-                        int have_focal /* the forward was given Yq */, void* ws, int64_t ws_bytes,
+                        int flags /* DENET_BWD_* */, void* ws, int64_t ws_bytes,
                         const denet_probe_t* probe, void* stream);
 
 #ifdef __cplusplus

@@ -204,6 +204,22 @@ def test_engine_deferred_losses_match_eager(name, dev):
         torch.cuda.synchronize()
         snaps.append([eng.losses.clone(), eng.dFq.clone(), eng.dFs.clone(), eng.grad_bucket.clone(),
                       eng.logits_full.clone(), eng.logits_binary.clone()])
+    # the backward in two calls (what bench.py does with more than one GPU: the gradient all-reduce
+    # starts after phase 1): phase 1 must leave dFs alone and complete everything else, phase 2 only dFs
+    eng.losses.zero_()
+    eng.forward(Fq, Fs, Ys, lab, Yq, Yf, wgt, P_, with_grad=True, defer_losses=True)
+    eng.dFs.fill_(-7.0)
+    eng.backward(Fq, lab, P_, phase=1)
+    torch.cuda.synchronize()
+    assert torch.all(eng.dFs == -7.0)
+    assert torch.equal(eng.grad_bucket, snaps[0][3]) and torch.equal(eng.dFq, snaps[0][1])
+    eng.grad_bucket.fill_(3.0)
+    eng.backward(Fq, lab, P_, phase=2)
+    torch.cuda.synchronize()
+    assert torch.all(eng.grad_bucket == 3.0)
+    eng.grad_bucket.copy_(snaps[0][3])
+    snaps.append([eng.losses.clone(), eng.dFq.clone(), eng.dFs.clone(), eng.grad_bucket.clone(),
+                  eng.logits_full.clone(), eng.logits_binary.clone()])
     for other in snaps[1:]:
         for a, b in zip(snaps[0], other):
             assert torch.equal(a, b)
