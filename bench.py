@@ -57,9 +57,11 @@ def kernel_bytes(s: EpisodeShape, sF: int):
         # dWn slabs || dFq: Fq twice (once per role), the two gradient slabs twice, dFq out, slabs out
         "bwd_dwn": 2 * N * C * P * sF + 4 * N * K * P * 4 + N * C * P * sF + N * n_part * K * C * 4 + N * K * C * 4,
         # per (group, slice) block: the label row of every slab + 16 columns of Wl + 16 rows of W2; outputs
-        "bwd_chain_dfq": G * nsl * (n_part * C + 32 * C) * 4 + 2 * B * C * 4 + B * nsl * C * 4,
+        # ... and the dweight role: every slab once
+        "bwd_chain_dfq": G * nsl * (n_part * C + 32 * C) * 4 + 2 * B * C * 4 + B * nsl * C * 4
+                         + N * n_part * K * C * 4 + K * C * 4,
         "bwd_params_dfs": B * C * P * sF + B * P * 4 + B * C * C * 4 + B * nsl * C * 4 + 6 * B * C * 4
-                          + N * n_part * K * C * 4 + 3 * C * C * 4,
+                          + 3 * C * C * 4,
     }
 
 
