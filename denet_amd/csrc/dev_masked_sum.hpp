@@ -44,6 +44,10 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     // depend on anything), so it arrives under the feature stream.  rows_per_block is 16 here.
     float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's att = S / (h*w)
     f32x4 w1v[4];
+    const int wq = threadIdx.x & 3, wog = threadIdx.x >> 2;
+    // the slice waits in LDS, not in registers, while the rows stream (16 live VGPRs more would take
+    // the kernel from 4 to 3 waves per SIMD): each thread parks and later re-reads its own 64 bytes
+    float* wsl = sm + ((P + 3) & ~3) + 4 + 16 + (int)threadIdx.x * 16;
     constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
@@ -102,21 +106,33 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     auto chain_tail = [&]() {
         if (W1 == nullptr) return;
         __syncthreads();
-        if ((int)threadIdx.x < C) {
-            float a = 0.f;
+        const f32x4 at = *reinterpret_cast<const f32x4*>(sl + 4 * wq);
+        float mine = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) a = fmaf(w1v[t >> 2][t & 3], sl[t], a);
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wsl + 4 * m);
+            float a = wv[0] * at[0];
+            a = fmaf(wv[1], at[1], a);
+            a = fmaf(wv[2], at[2], a);
+            a = fmaf(wv[3], at[3], a);
+            a += dpp_f32<0xB1>(a);                          // the quad's four column groups
+            a += dpp_f32<0x4E>(a);
+            mine = (wq == m) ? a : mine;                    // lane q keeps row og + 64 q
+        }
+        const int o = wog + 64 * wq;
+        if (o < C) {
             const int ncb = C / rows_per_block;
-            pre1_part[((int64_t)b * ncb + cblk) * C + threadIdx.x] = a;
+            pre1_part[((int64_t)b * ncb + cblk) * C + o] = mine;
         }
     };
     if (short_rows) issue(wave);
-    if (W1 != nullptr) {                                   // behind the feature loads in the queue
-        const float* wp = W1 + (int64_t)min((int)threadIdx.x, C - 1) * C + c0;
+    // W1 slice, behind the feature loads in the queue.  Four lanes share a row (16 B each, 64 B per
+    // row): a wave load touches 16 rows, four loads cover rows og, og+64, og+128, og+192.
+    if (W1 != nullptr) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) w1v[m] = *reinterpret_cast<const f32x4*>(wp + 4 * m);
+        for (int m = 0; m < 4; ++m)
+            w1v[m] = *reinterpret_cast<const f32x4*>(W1 + (int64_t)min(wog + 64 * m, C - 1) * C + c0 + 4 * wq);
     }
-
     // ---- the mask: gathered here from the int64 label map (K0 fused: nearest resize,
     // model/common.py:189-190; the block with cblk == 0 also writes mask[b,:] and cnt[b] for the backward
     // pass), or read from `mask`.
@@ -145,6 +161,10 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
     }
     __syncthreads();
+    if (W1 != nullptr) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(wsl + 4 * m) = w1v[m];
+    }
 
     if (short_rows) {
         consume(wave);

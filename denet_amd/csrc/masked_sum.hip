@@ -116,7 +116,7 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     if (W1 && ((C & 15) || C > 256)) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
-    size_t lds = (size_t)P * 4 + 32 + 64;
+    size_t lds = (size_t)P * 4 + 32 + 64 + (W1 ? 256 * 64 : 0);
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
                            (const float*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w,
