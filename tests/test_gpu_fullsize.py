@@ -208,6 +208,39 @@ def test_limits_and_duplicate_labels(dev):
         assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
 
 
+def test_many_ways_and_wide_channels(dev):
+    """Sliced-chain corners: more ways than the classifier block has thread groups (the novel rows are
+    then assembled in a second pass, K <= 32 runs eight waves per block), duplicate and out-of-range
+    labels among them, and shot = 8 at C = 256 (the widest gate/projection instantiation)."""
+    from denet_amd.synthetic import EpisodeShape, make_episodes
+    from oracle import denet_oracle as O
+    s = EpisodeShape("ways", N=2, way=10, shot=1, K=21, c=64, h=5, w=6, H=33, W=41, config_index=13)
+    ep = make_episodes(s, ignore_rows=1)
+    ep["label"][0] = torch.tensor([1, 2, 3, 4, 5, 6, 7, 8, 9, 3])        # way 9 overrides way 2
+    ep["label"][1] = torch.tensor([20, 19, 18, 17, 16, 15, 14, 13, 12, 11])
+    _, state, out = _run_step(s, dev, ep=ep)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["logits_binary"].cpu(), ref["logits_binary"]) < 2e-5
+    assert rel_err(out["Fq"].grad.cpu(), ref["dFq"]) < 1e-3
+    assert rel_err(out["Fs"].grad.cpu(), ref["dFs"]) < 1e-3
+    assert float(out["Fs"].grad[0, 2].abs().max()) == 0.0                 # the overridden way
+    for k, t in zip(ORDER, out["P"]):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
+
+    s2 = EpisodeShape("wide", N=2, way=2, shot=8, K=40, c=256, h=7, w=9, H=50, W=70, config_index=14, lam=1.5)
+    ep2 = make_episodes(s2, ignore_rows=1)
+    _, state2, out2 = _run_step(s2, dev, ep=ep2)
+    ref2 = O.head_step(ep2["Fq"], ep2["Fs"], ep2["Ys"], ep2["label"], ep2["Yq"], ep2["Yq_full"], ep2["wgt"], state2)
+    assert rel_err(out2["logits_full"].cpu(), ref2["logits_full"]) < 2e-5
+    assert rel_err(out2["loss_k"].cpu(), ref2["loss_k"]) < 1e-4
+    assert rel_err(out2["loss_p"].cpu(), ref2["loss_p"]) < 1e-4
+    assert rel_err(out2["Fq"].grad.cpu(), ref2["dFq"]) < 1e-3
+    assert rel_err(out2["Fs"].grad.cpu(), ref2["dFs"]) < 1e-3
+    for k, t in zip(ORDER, out2["P"]):
+        assert rel_err(t.grad.cpu(), ref2["d:" + k]) < 1e-3, k
+
+
 def test_unsupported_shapes_fail_loudly(dev):
     """No fallback path: shapes outside the kernels' limits raise instead of computing something else."""
     from denet_amd import _lib, ops
