@@ -137,7 +137,7 @@ __device__ unsigned long long* g_bstamps;
 #define BSTAMP(slot) do { if (threadIdx.x == 0) { \
         const size_t b__ = (size_t)blockIdx.y * gridDim.x + blockIdx.x; \
         g_bstamps[3 * b__ + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-        if ((slot) == 0) { unsigned id__; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id__)); g_bstamps[3 * b__ + 2] = id__; } } } while (0)
+        if ((slot) == 0) { unsigned id__, xc__; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id__)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc__)); g_bstamps[3 * b__ + 2] = ((unsigned long long)xc__ << 32) | id__; } } } while (0)
 #else
 #define BSTAMP(slot) do { } while (0)
 #endif

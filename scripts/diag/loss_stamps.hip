@@ -70,9 +70,19 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < 20; ++i) printf(" %d", he[i]);
                 printf("\n");
             }
-            // blocks per (xcc, se, cu) among CE blocks
-            int percu[8][64] = {{0}};
-            for (size_t b = 0; b < nblk / 2; ++b) { unsigned id = (unsigned)bs[3 * b + 2]; int cu = (id >> 8) & 0xf, sh = (id >> 12) & 1, se = (id >> 13) & 7; percu[0][0] += 0; (void)cu; (void)sh; (void)se; }
+            // CE blocks per CU (xcc, se, sh, cu) and the mean end time of the blocks by that count
+            std::vector<int> percu(8 * 8 * 2 * 16, 0);
+            auto cuof = [&](size_t b) { const unsigned long long v = bs[3 * b + 2]; const unsigned id = (unsigned)v, xc = (unsigned)(v >> 32) & 7;
+                                        return (int)((((xc * 8 + ((id >> 13) & 7)) * 2 + ((id >> 12) & 1)) * 16) + ((id >> 8) & 15)); };
+            for (size_t b = 0; b < nblk / 2; ++b) percu[cuof(b)]++;
+            int hist[12] = {0}; double endsum[12] = {0}; int endn[12] = {0};
+            for (int c : percu) hist[c < 11 ? c : 11]++;
+            for (size_t b = 0; b < nblk / 2; ++b) { const int c = percu[cuof(b)]; endsum[c < 11 ? c : 11] += (bs[3 * b + 1] - t0) * 0.01; endn[c < 11 ? c : 11]++; }
+            printf("CUs by number of CE blocks:");
+            for (int i = 0; i < 12; ++i) if (hist[i]) printf(" %d:%d", i, hist[i]);
+            printf("\nmean end time of CE blocks by their CU's count:");
+            for (int i = 1; i < 12; ++i) if (endn[i]) printf(" %d:%.1f", i, endsum[i] / endn[i]);
+            printf("\n");
         }
     }
     return 0;
