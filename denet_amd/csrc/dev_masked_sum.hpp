@@ -40,14 +40,21 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     float* mrow = mask + (int64_t)b * P;
     // Sliced chain, first mat-vec (gate layer 1, model/common.py:226) as a split-K partial: this block
     // owns att[c0..c0+16) of image b, so it can form  pre1_part[b][cblk][o] = sum_r W1[o][c0+r] * att[c0+r]
-    // for every output row o.  The 64-byte slice of W1 row o = tid is requested FIRST (it does not
-    // depend on anything), so it arrives under the feature stream.  rows_per_block is 16 here.
+    // for every output row o.  rows_per_block is 16 here.
     float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's att = S / (h*w)
-    f32x4 w1v[4];
     const int wq = threadIdx.x & 3, wog = threadIdx.x >> 2;
-    // the slice waits in LDS, not in registers, while the rows stream (16 live VGPRs more would take
-    // the kernel from 4 to 3 waves per SIMD): each thread parks and later re-reads its own 64 bytes
+    // W1 slice: four lanes share a row (16 B each, 64 B per row), four loads cover rows og, og+64,
+    // og+128, og+192.  It is requested behind the LAST round of feature loads (with the first round it
+    // delays the stream: 21.0 vs 20.3 us at C2 batch 8) and waits in LDS, each thread parking and
+    // re-reading its own 64 bytes.
     float* wsl = sm + ((P + 3) & ~3) + 4 + 16 + (int)threadIdx.x * 16;
+    auto fetch_w1 = [&]() {
+        if (W1 == nullptr) return;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            *reinterpret_cast<f32x4*>(wsl + 4 * m) =
+                *reinterpret_cast<const f32x4*>(W1 + (int64_t)min(wog + 64 * m, C - 1) * C + c0 + 4 * wq);
+    };
     constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
@@ -126,13 +133,6 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         }
     };
     if (short_rows) issue(wave);
-    // W1 slice, behind the feature loads in the queue.  Four lanes share a row (16 B each, 64 B per
-    // row): a wave load touches 16 rows, four loads cover rows og, og+64, og+128, og+192.
-    if (W1 != nullptr) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            w1v[m] = *reinterpret_cast<const f32x4*>(W1 + (int64_t)min(wog + 64 * m, C - 1) * C + c0 + 4 * wq);
-    }
     // ---- the mask: gathered here from the int64 label map (K0 fused: nearest resize,
     // model/common.py:189-190; the block with cblk == 0 also writes mask[b,:] and cnt[b] for the backward
     // pass), or read from `mask`.
@@ -161,21 +161,21 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
     }
     __syncthreads();
-    if (W1 != nullptr) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(wsl + 4 * m) = w1v[m];
-    }
 
     if (short_rows) {
         consume(wave);
+        bool fetched = false;
         for (int r = wave + 4 * NR; r < rows_per_block; r += 4 * NR) {
             issue(r);
+            if (r + 4 * NR >= rows_per_block) { fetch_w1(); fetched = true; }
             consume(r);
         }
+        if (!fetched) fetch_w1();
         chain_tail();
         return;
     }
     // ---- long rows: stream each row with a rolling loop
+    fetch_w1();
     for (int r = wave; r < rows_per_block; r += 4) {
         const int c = c0 + r;
         if (c >= C) break;
