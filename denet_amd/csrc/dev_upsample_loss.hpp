@@ -119,11 +119,22 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
 
     STAMP(0);
     const float* src = logits + (int64_t)n * K * h * w;
-#pragma unroll 4
-    for (int idx = tid; idx < K * ncol; idx += UL_T) {
-        const int k = idx / ncol, x = idx - k * ncol;
-        lg0[k * ncmax + x] = src[((int64_t)k * h + py) * w + cell_lo + x] * UL_LOG2E;
-        lg1[k * ncmax + x] = src[((int64_t)k * h + py1) * w + cell_lo + x] * UL_LOG2E;
+    {
+        // thread <-> (class, column) by shifts: the column count rounded up to a power of two (an integer
+        // division per element cost more than the loads it addressed)
+        const int xsh = 32 - __builtin_clz((unsigned)max(ncol - 1, 1));     // ncol <= 1 << xsh
+        const int x = tid & ((1 << xsh) - 1), kstep = UL_T >> xsh;
+        const int xc = min(x, ncol - 1);
+        const float* s0 = src + (int64_t)py * w + cell_lo + xc;
+        const float* s1 = src + (int64_t)py1 * w + cell_lo + xc;
+        const int64_t hw = (int64_t)h * w;
+        for (int k = tid >> xsh; k < K; k += kstep) {
+            const float v0 = s0[(int64_t)k * hw], v1 = s1[(int64_t)k * hw];
+            if (x < ncol) {
+                lg0[k * ncmax + x] = v0 * UL_LOG2E;
+                lg1[k * ncmax + x] = v1 * UL_LOG2E;
+            }
+        }
     }
     for (int k = tid; k < K; k += UL_T) wg[k] = (MODE == 0 && wgt) ? wgt[(int64_t)n * K + k] : 1.f;
     for (int c = tid; c <= ncell; c += UL_T) xs[c] = first_dst_ge(cell_lo + c, sx, w, W);
@@ -132,11 +143,29 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     const int xbase = xs[0], xw = xs[ncell] - xbase;      // label columns needed
     {
         const int64_t* Yn = Y + (int64_t)n * H * W + (int64_t)ys * W + xbase;
+        if (xw <= UL_T) {
+            // thread <-> (row, column) by shifts, the loads of up to four rows in flight together
+            const int lsh = 32 - __builtin_clz((unsigned)max(xw - 1, 1));
+            const int x = tid & ((1 << lsh) - 1), rstep = UL_T >> lsh;
+            const int64_t* col = Yn + min(x, xw - 1);
+            for (int r0 = tid >> lsh; r0 < rows; r0 += 4 * rstep) {
+                int64_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = col[(int64_t)min(r0 + u * rstep, rows - 1) * W];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * rstep;
+                    if (r < rows && x < xw)
+                        lab8[r * xw_max + x] = (v[u] >= 0 && v[u] < K) ? (unsigned char)v[u] : (unsigned char)UL_IGNORE;
+                }
+            }
+        } else {
 #pragma unroll 8
-        for (int i = tid; i < rows * xw; i += UL_T) {
-            const int r = i / xw, x = i - r * xw;
-            const int64_t v = Yn[(int64_t)r * W + x];
-            lab8[r * xw_max + x] = (v >= 0 && v < K) ? (unsigned char)v : (unsigned char)UL_IGNORE;
+            for (int i = tid; i < rows * xw; i += UL_T) {
+                const int r = i / xw, x = i - r * xw;
+                const int64_t v = Yn[(int64_t)r * W + x];
+                lab8[r * xw_max + x] = (v >= 0 && v < K) ? (unsigned char)v : (unsigned char)UL_IGNORE;
+            }
         }
         for (int x = tid; x < xw; x += UL_T) {
             int i0;
