@@ -257,3 +257,83 @@ def test_unsupported_shapes_fail_loudly(dev):
                                        ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
     with pytest.raises(_lib.DenetHipError):
         ops.masked_sum(torch.zeros(1, 64, 4, 4, dtype=torch.float16, device=dev), torch.zeros(1, 16, device=dev))
+
+
+@pytest.mark.parametrize("K", [21, 81])
+def test_c4_eval_1000_episodes_sharded_counts(dev, K):
+    """C4 (BASELINE.json configs[3]): test-time mIoU over 1000 synthetic episodes in batches of 20
+    (dataset/voc_sbd.py:268, config/test_config_denet.template:25), through FullIOU / BinaryIOU.
+    Size-independent properties at the full size: the counts of G = 2, 4, 8 contiguous episode shards
+    add up to the single-stream matrix bit for bit (what the int64 all-reduce of SURVEY.md §8e does),
+    every valid pixel is counted exactly once, mean_iou is the same float64 for every G, and
+    BinaryIOU's first-seen class order is restored from the shards' order keys.  The first two batches
+    are also checked against the oracle (up-sample + arg-max + bincount on the host)."""
+    from denet_amd.metrics import BinaryIOU, FullIOU
+    from oracle import denet_oracle as O
+    E, NB, h, w, H, W = 1000, 20, 41, 41, 321, 321
+
+    def batch(b):
+        g = torch.Generator(device=dev).manual_seed(4000 + 97 * K + b)
+        logits = 3.0 * torch.randn(NB, K, h, w, device=dev, generator=g)
+        yt = torch.randint(0, K, (NB, H, W), device=dev, generator=g)
+        yt[:, :8] = 255
+        binl = 3.0 * torch.randn(NB, 2, h, w, device=dev, generator=g)
+        yq = torch.randint(0, 2, (NB, H, W), device=dev, generator=g)
+        if b % 7 == 0:
+            yq[3] = 0                                     # no foreground: BinaryIOU skips the sample
+        cls = torch.randint(1, K, (NB,), device=dev, generator=g)
+        return logits, yt, binl, yq, cls
+
+    nbatch = E // NB
+    per_batch, valid = [], 0
+    single_f, single_b = FullIOU(K), BinaryIOU()
+    for b in range(nbatch):
+        logits, yt, binl, yq, cls = batch(b)
+        single_f.update(yt, logits)
+        single_b.update(yq, binl, cls)
+        one = FullIOU(K)
+        one.update(yt, logits)
+        per_batch.append(one.counts())
+        valid += int((yt != 255).sum())
+        if b < 2 and K == 21:
+            up = O.upsample(logits.cpu(), (H, W))
+            top = up.topk(2, dim=1)[0]
+            assert float((top[:, 0] - top[:, 1]).min()) >= 0.0
+            ytc = yt.cpu().clone()
+            ytc[(top[:, 0] - top[:, 1]) <= 1e-4] = 255    # sub-margin pixels out of both sides (SURVEY.md §7)
+            chk = FullIOU(K)
+            chk.update(ytc.to(dev), logits)
+            assert np.array_equal(chk.counts(), O.confusion_matrix(ytc.numpy(), up.argmax(1).numpy(), K))
+    ref = single_f.counts()
+    assert int(ref.sum()) == valid
+    assert np.array_equal(sum(per_batch), ref)
+    miou, biou = single_f.mean_iou(), single_b.mean_iou()
+    order = list(single_b.inter.keys())
+    for G in (2, 4, 8):
+        shard = nbatch // G                               # contiguous blocks of the episode stream per rank
+        mats, bs = [], []
+        for r in range(G):
+            f, bi = FullIOU(K), BinaryIOU()
+            lo = r * shard
+            hi = nbatch if r == G - 1 else lo + shard
+            for b in range(lo, hi):
+                logits, yt, binl, yq, cls = batch(b)
+                f.update(yt, logits)
+                bi.update(yq, binl, cls, order_keys=np.arange(b * NB, (b + 1) * NB))
+            mats.append(f.counts())
+            bs.append(bi)
+        merged = FullIOU(K)
+        merged.update_counts(sum(mats))
+        assert np.array_equal(merged.counts(), ref)
+        assert merged.mean_iou() == miou                  # same integers -> same float64
+        # what BinaryIOU.all_reduce does with SUM / MIN collectives, on the host
+        inter, union, first = {}, {}, {}
+        for bi in bs:
+            for c in bi.inter:
+                inter[c] = inter.get(c, 0.0) + bi.inter[c]
+                union[c] = union.get(c, 0.0) + bi.union[c]
+                first[c] = min(first.get(c, 1 << 62), bi._first[c])
+        seq = sorted(first, key=lambda c: first[c])
+        assert seq == order
+        assert float(np.mean([inter[c] / union[c] for c in seq])) == biou
+        assert all(inter[c] == single_b.inter[c] and union[c] == single_b.union[c] for c in seq)
