@@ -10,8 +10,7 @@ to dFq, dFs and the seven estimator parameter gradients (SURVEY.md §8d
 "boundary being timed").  Feature producer and optimizer are excluded, as in
 the metric's definition.  With N > 1 each rank owns its own batch (episodes are
 independent: weak scaling) and the step contains ONE RCCL all-reduce (AVG) of
-the flat parameter-gradient bucket, started as soon as the bucket is complete
-and overlapped with the last kernel's dFs stream.
+the flat parameter-gradient bucket, enqueued behind the backward.
 
 Rank 0 prints one JSON line.  `roofline` is for the dominant kernel, timed with
 HIP events on the launch stream inside the timed region; `cpu_baseline` is the
@@ -129,6 +128,10 @@ def main():
     # gloo (dry runs only) has no AVG: it sums, which is the same exchange
     reduce_op = None if dist is None else (dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
 
+    # dry runs over gloo reduce through host memory (gloo's device-tensor path was seen to hang with two
+    # ranks on one GPU); RCCL reduces the device bucket in place
+    host_reduce = dist is not None and dist.get_backend() != "nccl"
+
     shape = CONFIGS[args.config]
     if args.episodes > 0:
         shape = EpisodeShape(**{**shape.asdict(), "N": args.episodes})
@@ -143,18 +146,26 @@ def main():
     eng = HeadStepEngine(N, way, shape.shot, shape.K, shape.c, shape.h, shape.w, shape.H, shape.W, dev, fdt)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # the step's buffers never change: bind the arguments once, so a step costs ~20 us of host time
+    # (two library calls) instead of ~40 us of ctypes argument conversion
+    eng.bind_step(ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params)
+
     def step():
-        eng.forward(ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params, with_grad=True,
-                    defer_losses=True)
-        if world == 1:
-            eng.backward(ep["Fq"], labels, params)
-        else:
-            # every gradient except dFs, then the bucket's all-reduce on RCCL's stream while the 70 MB
-            # dFs stream (which nothing in the step reads) runs on ours; the step ends when both have
-            eng.backward(ep["Fq"], labels, params, phase=1)
-            work = dist.all_reduce(eng.grad_bucket, op=reduce_op, async_op=True)
-            eng.backward(ep["Fq"], labels, params, phase=2)
-            work.wait()
+        st = torch.cuda.current_stream().cuda_stream if args.graph else stream     # capture runs on a side stream
+        eng.run_forward(st)
+        eng.run_backward(0, st)
+        if world > 1:
+            # ONE all-reduce of the flat parameter-gradient bucket, enqueued behind the backward.
+            # Measured on a one-rank RCCL group (scripts/diag_enqueue.py): splitting the last launch
+            # (DENET_BWD_NO_DFS / ONLY_DFS) to overlap the all-reduce with the dFs stream costs 7 us for
+            # the extra launch and 12 us more for running two hardware queues side by side -- 128.6 us
+            # per step against 110.2 us for this order.
+            if host_reduce:
+                buf = eng.grad_bucket.cpu()
+                dist.all_reduce(buf, op=reduce_op)
+                eng.grad_bucket.copy_(buf)
+            else:
+                dist.all_reduce(eng.grad_bucket, op=reduce_op)
 
     dbg = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("DENET_BENCH_DEBUG") else (lambda m: None)
     if os.environ.get("DENET_BENCH_DEBUG"):
@@ -228,7 +239,7 @@ def main():
     dbg("timed region done")
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_reduce else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

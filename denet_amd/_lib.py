@@ -136,6 +136,41 @@ def call(name: str, *args):
         raise DenetHipError(f"{name} failed: {strerror(rc)} (code {rc})")
 
 
+def _convert(name, args):
+    sig = _SIGS[name]
+    if len(args) != len(sig):
+        raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
+    conv = []
+    for c, a in zip(sig, args):
+        if c == "p":
+            conv.append(_ptr(a))
+        elif c == "h":
+            conv.append(None if a is None else ctypes.cast(ctypes.pointer(a), ctypes.c_void_p))
+        elif c == "f":
+            conv.append(float(a))
+        else:
+            conv.append(int(a))
+    return conv
+
+
+def bind(name: str, *args):
+    """Pre-convert the arguments of `name` once and return `run(stream_handle)`.  For loops that call
+    the same entry point on the same buffers every iteration (the argument conversion of the ~40
+    arguments of the fused step costs more host time than the launches themselves).  The caller keeps
+    the tensors alive and unchanged in place (same data_ptr) for as long as it uses `run`."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = tuple(_convert(name, args))
+    keep = args                                            # the bound buffers stay referenced
+
+    def run(stream):
+        rc = fn(*conv, stream)
+        if rc != 0:
+            raise DenetHipError(f"{name} failed: {strerror(rc)} (code {rc})")
+    run.keep = keep
+    return run
+
+
 def query(name: str, *args) -> int:
     return int(getattr(load(), name)(*[int(a) for a in args]))
 

@@ -44,17 +44,61 @@ class HeadStepEngine:
         self._probe = None
         self._deferred = False
         self._have_focal = True
+        self._bound = None
+        self._bound_args = None
 
     def set_probe(self, which, start_event, stop_event):
         """Bracket kernel `which` (a name in _lib.KERNEL_IDS, or None) with HIP events."""
         if which is None:
             self._probe = None
+            self._rebind()
             return
         p = _lib.Probe()
         p.which = _lib.KERNEL_IDS[which]
         p.start = start_event.h
         p.stop = stop_event.h
         self._probe = p
+        self._rebind()
+
+    # ---- bound step: the same buffers every iteration (training loops over resident batches, bench) ----
+    def bind_step(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
+                  grad_loss_k=None):
+        """Fix the step's arguments (with_grad, deferred losses): run_forward() / run_backward(phase)
+        then only make the library calls -- the argument conversion is done once here.  The tensors must
+        stay alive and in place."""
+        self._bound_args = (Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k)
+        self._rebind()
+
+    def _rebind(self):
+        if self._bound_args is None:
+            return
+        Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k = self._bound_args
+        N, way, shot, K, C, h, w, H, W = self.dims
+        P = [params[k] for k in PARAM_ORDER]
+        deferred = Yq_full is not None
+        have_focal = Yq is not None
+        g = self.grads
+        fwd = _lib.bind("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask,
+                        weight_mask, N, way, shot, K, C, h, w, H, W,
+                        _lib.GRAD_DEFER_LOSSES if deferred else 1, self.logits_full, self.logits_binary,
+                        self.losses, self.ws, self.ws_bytes, self._probe)
+        bwd = {}
+        for phase, fl in ((0, 0), (1, _lib.BWD_NO_DFS), (2, _lib.BWD_ONLY_DFS)):
+            bwd[phase] = _lib.bind(
+                "denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
+                params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
+                N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
+                g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
+                g["map.linear.bias"], self.losses if deferred else None,
+                (_lib.BWD_HAVE_FOCAL if have_focal else 0) | fl, self.ws, self.ws_bytes, self._probe)
+        self._bound = (fwd, bwd, deferred, have_focal)
+
+    def run_forward(self, stream=None):
+        fwd, _, self._deferred, self._have_focal = self._bound
+        fwd(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+
+    def run_backward(self, phase=0, stream=None):
+        self._bound[1][phase](torch.cuda.current_stream().cuda_stream if stream is None else stream)
 
     def forward(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
                 with_grad=True, defer_losses=False):
