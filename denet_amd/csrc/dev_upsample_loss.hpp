@@ -66,6 +66,7 @@ struct LossArgs {
     int K, h, w, H, W, xsplit, rows_max, emax, xw_max;
     float alpha, gamma;
     float *part, *dlog_a, *dlog_b;
+    float dw;            // UNI kernels: the step of the horizontal lerp weight between neighbouring label columns
 };
 
 // Body for block (episode n, bx = py * xsplit + xsid); 256 threads; sm: the geometry's LDS bytes.
@@ -74,7 +75,18 @@ struct LossArgs {
 // register plus an immediate offset instead of a v_add per access (8 of 52 issue slots per four
 // pixel-classes in the gradient pass: 34.4 -> 33.4 us).  NCM = 0: run-time stride.  (The class count as
 // a constant as well, K = 21 fully unrolled, measured slower: 36.3 us.)
-template <int MODE, bool GRAD, int NCM = 0>
+//
+// UNI (weighted CE with gradient only): the launcher has verified, with the device's own float
+// arithmetic, that inside every cell the horizontal lerp weights of consecutive label columns are an
+// exact arithmetic progression with step g.dw (true whenever (w-1)/(W-1) is a power of two: 41 -> 321).
+// The shifted exponent of a class is linear in that weight, so along a cell row
+//   exp2(x[e+1] - U[e+1]) = exp2(x[e] - U[e]) * rho,   rho = exp2((d - dM) * dw)
+// and one multiplication replaces fma + sub + v_exp_f32 (a quarter-rate instruction) per pixel-class in
+// both phases; two exponentials per (row, cell half, class) start the chain.  Chains whose exponent
+// moves by more than 100 octaves per cell (a first element that underflows must not hide a later one
+// that matters) and pixels whose exponentials all underflow take the generic arithmetic, and a block that
+// met either runs the generic gradient pass.
+template <int MODE, bool GRAD, int NCM = 0, bool UNI = false>
 __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int bx, float* sm) {
     const float* __restrict__ logits = g.logits;
     const int64_t* __restrict__ Y = g.Y;
@@ -111,6 +123,10 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     off = (off + ncmax + 2 + 1) & ~1;
     f32x2* stats = reinterpret_cast<f32x2*>(sm + off);    // [rows_max][emax][ncmax] (shift, weight/sumexp), GRAD
     off += GRAD ? 2 * rows_max * emax * ncmax : 0;
+    f32x2* mst = reinterpret_cast<f32x2*>(sm + off);      // [rows_max][ncmax] (Ma, Mb - Ma) of each (row, cell), GRAD
+    off += GRAD ? 2 * rows_max * ncmax : 0;
+    int* slowf = reinterpret_cast<int*>(sm + off);        // UNI: some item of the block left the fast arithmetic
+    off += GRAD ? 2 : 0;
     unsigned char* lab8 = reinterpret_cast<unsigned char*>(sm + off);   // [rows_max][xw_max]
 
     const float sy = bilinear_scale(h, H), sx = bilinear_scale(w, W);
@@ -137,6 +153,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
         }
     }
     for (int k = tid; k < K; k += UL_T) wg[k] = (MODE == 0 && wgt) ? wgt[(int64_t)n * K + k] : 1.f;
+    if (UNI && tid == 0) slowf[0] = 0;
     for (int c = tid; c <= ncell; c += UL_T) xs[c] = first_dst_ge(cell_lo + c, sx, w, W);
     __syncthreads();
     STAMP(1);
@@ -199,6 +216,12 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             Ma = fmaxf(Ma, h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl]);
             Mb = fmaxf(Mb, h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]);
         }
+        if (UNI && hf == 0) {
+            f32x2 m2;
+            m2[0] = Ma;
+            m2[1] = Mb - Ma;
+            mst[r * ncmax + cl] = m2;
+        }
         for (int x0 = xb; x0 < xe; x0 += UL_CH) {
             const int cntx = min(UL_CH, xe - x0);
             float w1[UL_CH], U[UL_CH], se[UL_CH];
@@ -211,18 +234,37 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
                 U[e] = (1.f - w1[e]) * Ma + w1[e] * Mb;
                 se[e] = 0.f;
             }
-#pragma unroll 3
-            for (int k = 0; k < K; ++k) {
-                const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
-                const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
-#pragma unroll
-                for (int e = 0; e < UL_CH; ++e) se[e] += __builtin_amdgcn_exp2f(fmaf(w1[e], d, a) - U[e]);
-            }
             bool under = false;
+            if constexpr (UNI) {
+                const float dM = Mb - Ma, dw = g.dw;
+                float dmax = 0.f;
+#pragma unroll 3
+                for (int k = 0; k < K; ++k) {
+                    const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
+                    const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
+                    const float a2 = a - Ma, d2 = d - dM;
+                    dmax = fmaxf(dmax, fabsf(d2));
+                    float E = __builtin_amdgcn_exp2f(fmaf(w1[0], d2, a2));
+                    const float rho = __builtin_amdgcn_exp2f(d2 * dw);
+                    se[0] += E;
+#pragma unroll
+                    for (int e = 1; e < UL_CH; ++e) { E *= rho; se[e] += E; }
+                }
+                under = !(dmax <= 100.f);
+            } else {
+#pragma unroll 3
+                for (int k = 0; k < K; ++k) {
+                    const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
+                    const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
+#pragma unroll
+                    for (int e = 0; e < UL_CH; ++e) se[e] += __builtin_amdgcn_exp2f(fmaf(w1[e], d, a) - U[e]);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < UL_CH; ++e) under = under || !(se[e] > 1e-30f);
             if (under) {
                 // exact per-pixel max (rare): every exponential underflowed against the bound
+                if constexpr (UNI) slowf[0] = 1;
 #pragma unroll
                 for (int e = 0; e < UL_CH; ++e) U[e] = -INFINITY;
                 for (int k = 0; k < K; ++k) {
@@ -289,6 +331,8 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
 
     // ---------------- phase 2 ----------------
     const int rmid = (rows + 1) >> 1;
+    const bool fastp = UNI && slowf[0] == 0;
+    const float dwv = g.dw;
     for (int item = tid; item < K * ncell * 2; item += UL_T) {
         const int rh = item / (K * ncell);
         const int kcx = item - rh * (K * ncell);
@@ -310,14 +354,32 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             float gS = 0.f, gB = 0.f;
             const f32x2* strow = stats + (r * emax) * ncmax + cl;
             const unsigned char* lrow = lab8 + r * xw_max + (x0 - xbase);
+            if (UNI && fastp) {
+                const f32x2 m2 = mst[r * ncmax + cl];
+                const float d2 = d - m2[1];
+                float w1 = wrow[0];
+                float E = __builtin_amdgcn_exp2f(fmaf(w1, d2, a - m2[0]));
+                const float rho = __builtin_amdgcn_exp2f(d2 * dwv);
+                const float* srow = reinterpret_cast<const float*>(strow) + 1;
 #pragma unroll 4
-            for (int e = 0; e < nx; ++e) {
-                const float w1 = wrow[e];
-                const f32x2 st = strow[e * ncmax];
-                float g = __builtin_amdgcn_exp2f(fmaf(w1, d, a) - st[0]) * st[1];
-                g -= ((int)lrow[e] == k) ? wk : 0.f;
-                gS += g;
-                gB += g * w1;
+                for (int e = 0; e < nx; ++e) {
+                    float g = E * srow[e * 2 * ncmax];
+                    g -= ((int)lrow[e] == k) ? wk : 0.f;
+                    gS += g;
+                    gB += g * w1;
+                    E *= rho;
+                    w1 += dwv;
+                }
+            } else {
+#pragma unroll 4
+                for (int e = 0; e < nx; ++e) {
+                    const float w1 = wrow[e];
+                    const f32x2 st = strow[e * ncmax];
+                    float g = __builtin_amdgcn_exp2f(fmaf(w1, d, a) - st[0]) * st[1];
+                    g -= ((int)lrow[e] == k) ? wk : 0.f;
+                    gS += g;
+                    gB += g * w1;
+                }
             }
             const float gA = gS - gB;                   // sum of g*(1-w1)
             L0 += h0 * gA; L1 += h1 * gA;
@@ -351,10 +413,10 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     STAMP(6);
 }
 
-template <int MODE, bool GRAD, int NCM = 0>
+template <int MODE, bool GRAD, int NCM = 0, bool UNI = false>
 __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    upsample_loss_body<MODE, GRAD, NCM>(g, blockIdx.y, blockIdx.x, sm);
+    upsample_loss_body<MODE, GRAD, NCM, UNI>(g, blockIdx.y, blockIdx.x, sm);
 }
 
 // Weighted CE (blockIdx.y < N0) and binary focal (the rest) in ONE launch: the two losses read
@@ -364,12 +426,12 @@ __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
 // focal blocks run in the fifth slot and in the slots CE blocks free.  Measured slower: the focal
 // tiles inside the CE blocks (42 us), 6 or 8 waves per SIMD by capping registers (spills), four row
 // groups in phase 2 (LDS then limits a CU to 4 blocks), a cell-level soft-max shift in phase 1.
-template <bool GRAD, int NCM = 0>
+template <bool GRAD, int NCM = 0, bool UNI = false>
 __global__ __launch_bounds__(UL_T) void upsample_loss_pair_kernel(LossArgs g0, LossArgs g1, int N0, int nb0, int nb1) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BSTAMP(0);
     if ((int)blockIdx.y < N0) {
-        if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD, NCM>(g0, blockIdx.y, blockIdx.x, sm);
+        if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD, NCM, UNI>(g0, blockIdx.y, blockIdx.x, sm);
     } else {
         if ((int)blockIdx.x < nb1) upsample_loss_body<1, false>(g1, blockIdx.y - N0, blockIdx.x, sm);
     }

@@ -123,6 +123,7 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         size_t off = (size_t)(2 + (grad ? 8 : 0)) * K * ncmax + K + 8 + xw_max;
         off = (off + ncmax + 2 + 1) & ~(size_t)1;
         off += grad ? (size_t)2 * rows_max * emax * ncmax : 0;
+        off += grad ? (size_t)2 * rows_max * ncmax + 2 : 0;   // per-(row, cell) shift pair + the fast-path flag
         size_t lds = off * 4 + (size_t)rows_max * xw_max;
         lds = (lds + 15) & ~(size_t)15;
         if (lds <= 64 * 1024 || (cw == 1 && lds <= 150 * 1024)) {
@@ -143,14 +144,25 @@ extern "C" int64_t denet_upsample_loss_parts(int64_t K, int64_t h, int64_t w, in
     return (int64_t)h * g.xsplit;
 }
 
+// The uniform-step kernels (UNI) apply when the horizontal scale (w-1)/(W-1) is a power of two: then
+// scale * x is exact in fp32 for every label column x, so the lerp weights inside a cell are an exact
+// arithmetic progression with step `scale` (dev_upsample_loss.hpp).
+static float uniform_step(int w, int W) {
+    const float sx = bilinear_scale(w, W);
+    if (!(sx > 0.f) || sx >= 1.f) return 0.f;
+    int ex;
+    return frexpf(sx, &ex) == 0.5f ? sx : 0.f;
+}
+
 static int launch_loss(int mode, bool grad, const float* logits, const int64_t* Y, const float* wgt, int64_t N,
                        int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, float alpha, float gamma, float* part,
                        float* da, float* db, hipStream_t st) {
     LossGeom g;
     if (!loss_geom((int)K, (int)h, (int)w, (int)H, (int)W, grad, &g)) return DENET_E_UNSUPPORTED;
     dim3 grid((unsigned)(h * g.xsplit), (unsigned)N), block((unsigned)g.threads);
+    const float dw = uniform_step((int)w, (int)W);
     LossArgs a{logits, Y, wgt, (int)K, (int)h, (int)w, (int)H, (int)W, g.xsplit, g.rows_max, g.emax, g.xw_max,
-               alpha, gamma, part, da, db};
+               alpha, gamma, part, da, db, dw};
 #define UL_GO(M, G)                                                                                          \
     {                                                                                                        \
         int rc = set_lds(upsample_loss_kernel<M, G>, g.lds);                                                 \
@@ -165,7 +177,15 @@ static int launch_loss(int mode, bool grad, const float* logits, const int64_t* 
     }
     if (mode == 0) {
         if (grad) {
-            if (g.ncmax == 16) UL_GO3(0, true, 16) else UL_GO(0, true)
+            if (g.ncmax == 16 && dw > 0.f) {
+                int rc = set_lds(upsample_loss_kernel<0, true, 16, true>, g.lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((upsample_loss_kernel<0, true, 16, true>), grid, block, g.lds, st, a);
+            } else if (dw > 0.f) {
+                int rc = set_lds(upsample_loss_kernel<0, true, 0, true>, g.lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((upsample_loss_kernel<0, true, 0, true>), grid, block, g.lds, st, a);
+            } else if (g.ncmax == 16) UL_GO3(0, true, 16) else UL_GO(0, true)
         } else UL_GO(0, false)
     } else {
         UL_GO(1, false)
@@ -183,18 +203,27 @@ int denet_loss_pair_fwd(const float* logits, const int64_t* Yq_full, const float
                         void* stream) {
     LossGeom g0, g1;
     const bool grad = da != nullptr;
+    const float dw = uniform_step((int)w, (int)W);
     if (!loss_geom((int)K, (int)h, (int)w, (int)H, (int)W, grad, &g0)) return DENET_E_UNSUPPORTED;
     if (!loss_geom(2, (int)h, (int)w, (int)H, (int)W, false, &g1)) return DENET_E_UNSUPPORTED;
     if (N + NB > 65535) return DENET_E_UNSUPPORTED;
     const int nb0 = (int)h * g0.xsplit, nb1 = (int)h * g1.xsplit;
     const size_t lds = g0.lds > g1.lds ? g0.lds : g1.lds;
     LossArgs a0{logits, Yq_full, wgt, (int)K, (int)h, (int)w, (int)H, (int)W, g0.xsplit, g0.rows_max, g0.emax,
-                g0.xw_max, 0.f, 0.f, part_k, da, db};
+                g0.xw_max, 0.f, 0.f, part_k, da, db, dw};
     LossArgs a1{logits_binary, Yq, nullptr, 2, (int)h, (int)w, (int)H, (int)W, g1.xsplit, g1.rows_max, g1.emax,
-                g1.xw_max, alpha, gamma, part_p, nullptr, nullptr};
+                g1.xw_max, alpha, gamma, part_p, nullptr, nullptr, 0.f};
     dim3 grid((unsigned)(nb0 > nb1 ? nb0 : nb1), (unsigned)(N + NB)), block(UL_T);
     hipStream_t st = (hipStream_t)stream;
-    if (grad && g0.ncmax == 16) {
+    if (grad && dw > 0.f && g0.ncmax == 16) {
+        int rc = set_lds(upsample_loss_pair_kernel<true, 16, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 16, true>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
+    } else if (grad && dw > 0.f) {
+        int rc = set_lds(upsample_loss_pair_kernel<true, 0, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 0, true>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
+    } else if (grad && g0.ncmax == 16) {
         int rc = set_lds(upsample_loss_pair_kernel<true, 16>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 16>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);

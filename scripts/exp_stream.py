@@ -11,7 +11,7 @@ def t(fn, reps=50):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 from denet_amd._lib import call, feat_code
-for B in (40, 640):
+for B in (40, 200, 640):
     C, h, w, H, W = 256, 41, 41, 321, 321
     Fs = torch.randn(B, C, h, w, device=dev)
     Ys = torch.randint(0, 2, (B, H, W), device=dev)
