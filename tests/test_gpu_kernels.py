@@ -239,3 +239,35 @@ def test_engine_deferred_losses_match_eager(name, dev):
     assert rel_err(snaps[0][2].reshape(ep["Fs"].shape).cpu(), z["out:dFs"]) < TOL
     for k in PARAM_ORDER:
         assert rel_err(eng.grads[k].cpu(), z["grad:" + k]) < TOL, k
+
+
+@pytest.mark.parametrize("geom", [(9, 9, 65, 65), (5, 13, 33, 97), (6, 7, 41, 50)])
+def test_loss_kernel_extreme_logits(geom, dev):
+    """Logit swings of hundreds of nats between neighbouring positions: every exponential of a pixel
+    underflows against the blended bound (exact-max fallback), and on power-of-two scales (the first two
+    geometries) the multiplication chains of the uniform-step path are too steep and the block falls
+    back to the generic gradient pass.  Loss and gradient must still match stock PyTorch."""
+    import torch.nn.functional as F
+    from denet_amd import ops
+    h, w, H, W = geom
+    N, K = 3, 5
+    g = torch.Generator().manual_seed(77 + h)
+    logits = torch.randn(N, K, h, w, generator=g)
+    hot = torch.randint(0, K, (N, h, w), generator=g)
+    logits[0] += 400.0 * F.one_hot(hot[0], K).permute(2, 0, 1)         # a different class wins by 400 at each position
+    logits[1] += 120.0 * torch.randn(K, h, w, generator=g)            # steep but mostly representable
+    y = torch.randint(0, K, (N, H, W), generator=g)
+    y[:, :3] = 255
+    wgt = torch.ones(N, K)
+    wgt[:, 2] = 2.5
+    ref_in = logits.clone().requires_grad_(True)
+    up = F.interpolate(ref_in, size=(H, W), mode="bilinear", align_corners=True)
+    per = [F.cross_entropy(up[n:n + 1], y[n:n + 1], weight=wgt[n], ignore_index=255) for n in range(N)]
+    ref = torch.stack(per).mean()
+    ref.backward()
+    loss, per_dev, scale, da, db = ops.upsample_wce(logits.to(dev), y.to(dev), wgt.to(dev), grad=True)
+    dl = ops.combine_slabs(da, db, scale, None)
+    torch.cuda.synchronize()
+    assert rel_err(loss.cpu(), ref.detach()) < 1e-5
+    assert rel_err(per_dev.cpu(), torch.stack(per).detach()) < 1e-5
+    assert rel_err(dl.cpu(), ref_in.grad) < 1e-4
