@@ -3,13 +3,14 @@
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
-int main() {
-    const int N = 8, way = 1, K = 21, C = 256, P = 1681;
+#include <cstdlib>
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 8, way = argc > 2 ? atoi(argv[2]) : 1, K = argc > 3 ? atoi(argv[3]) : 21, C = 256, P = argc > 4 ? atoi(argv[4]) : 1681;
     float *Fq, *Wn, *logits, *bin; int64_t* labels;
     CK(hipMalloc(&Fq, (size_t)N * C * P * 4)); CK(hipMalloc(&Wn, N * K * C * 4)); CK(hipMalloc(&logits, N * K * P * 4));
-    CK(hipMalloc(&bin, N * 2 * P * 4)); CK(hipMalloc(&labels, N * 8));
+    CK(hipMalloc(&bin, (size_t)N * way * 2 * P * 4)); CK(hipMalloc(&labels, N * way * 8));
     CK(hipMemset(Fq, 0, (size_t)N * C * P * 4)); CK(hipMemset(Wn, 0, N * K * C * 4));
-    std::vector<int64_t> l(N, 3); CK(hipMemcpy(labels, l.data(), N * 8, hipMemcpyHostToDevice));
+    std::vector<int64_t> l(N * way, 3); for (int i = 0; i < N * way; ++i) l[i] = 3 + (i % way); CK(hipMemcpy(labels, l.data(), N * way * 8, hipMemcpyHostToDevice));
     unsigned long long* d_st; CK(hipMalloc(&d_st, 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
     float* junk; CK(hipMalloc(&junk, 512u << 20));
