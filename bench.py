@@ -314,6 +314,7 @@ def main():
         # line had been printed; there is nothing left to clean up.
         sys.stdout.flush()
         sys.stderr.flush()
+        time.sleep(0.5)          # let slower ranks drain their side of the last collective first
         os._exit(0)
 
 
