@@ -272,6 +272,23 @@ def main():
     step_roof = {"bytes_per_episode": spb, "achieved": round(value / world * spb / 1e9, 1), "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": round(value / world * spb / 1e9 / HBM_PEAK_GBS, 4)}
 
+    # the box's own stream-copy ceiling (read + write bytes of a 512 MiB device copy), for reading the
+    # fractions above against what this HBM delivers rather than the 8 TB/s specification
+    copy_gbs = None
+    if rank == 0:
+        a = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            b.copy_(a)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(10 * 2 * a.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        del a, b
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import denet_oracle as O            # checker only: CPU baseline leg
@@ -302,7 +319,8 @@ def main():
                                    f"features {shape.c}x{shape.h}x{shape.w}, labels {shape.H}x{shape.W}",
                        "episodes_per_gpu": N, "global_batch": N * world, "parallelism": f"dp{world} (episode-sharded)",
                        "graph_replay": bool(graph)},
-            "roofline": roofline, "step_roofline": step_roof, "hbm_stream_kernels": streams, "cpu_baseline": cpu,
+            "roofline": roofline, "step_roofline": step_roof, "hbm_stream_kernels": streams,
+            "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu,
             "kernels_us": {k: round(v, 2) for k, v in breakdown.items()},
             "loss_k": losses[0], "loss_p": losses[1],
         }

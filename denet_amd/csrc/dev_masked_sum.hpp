@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
     // 1-D grid of ncb * B blocks; the ncb channel blocks of an image are placed on one XCD (shared gather)
     const int ncb = (C + rows_per_block - 1) / rows_per_block;
     const int v = xcd_swizzle(blockIdx.x, gridDim.x);
+    BSTAMP(0);
     masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
                            pre1_part);
+    BSTAMP(1);
 }
 
 // ---------------------------------------------------------------------------
