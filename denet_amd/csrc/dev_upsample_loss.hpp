@@ -357,19 +357,21 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             if (UNI && fastp) {
                 const f32x2 m2 = mst[r * ncmax + cl];
                 const float d2 = d - m2[1];
-                float w1 = wrow[0];
+                const float w1 = wrow[0];
                 float E = __builtin_amdgcn_exp2f(fmaf(w1, d2, a - m2[0]));
                 const float rho = __builtin_amdgcn_exp2f(d2 * dwv);
                 const float* srow = reinterpret_cast<const float*>(strow) + 1;
+                // sum_e w1[e] g[e] with w1[e] = w1[0] + e dw:  sum_e e g[e] = nx * gS - sum_e (g[0] + .. + g[e])
+                float pre = 0.f;
 #pragma unroll 4
                 for (int e = 0; e < nx; ++e) {
                     float g = E * srow[e * 2 * ncmax];
                     g -= ((int)lrow[e] == k) ? wk : 0.f;
                     gS += g;
-                    gB += g * w1;
+                    pre += gS;
                     E *= rho;
-                    w1 += dwv;
                 }
+                gB = fmaf(dwv, fmaf((float)nx, gS, -pre), w1 * gS);
             } else {
 #pragma unroll 4
                 for (int e = 0; e < nx; ++e) {
