@@ -189,10 +189,17 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
         const int t0 = head + nvec * V;
         const float tv1 = FeatIO<T>::load(row + min(t0 + lane, P - 1));
-#pragma unroll 4
-        for (int i = lane; i < nvec; i += 64) {
-            vec_t vv = rv[i];
-            acc += Vec16<T>::dot(vv, sm + head + i * V);
+        // eight clamped, unconditional vector loads in flight per lane and trip (8 KB per wave)
+        for (int i0 = lane; i0 < nvec; i0 += 64 * NV) {
+            vec_t vv[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) vv[u] = rv[min(i0 + 64 * u, nvec - 1)];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = i0 + 64 * u;
+                const float d = Vec16<T>::dot(vv[u], sm + head + min(i, nvec - 1) * V);
+                acc += (i < nvec) ? d : 0.f;
+            }
         }
         acc += (t0 + lane < P) ? tv1 * sm[min(t0 + lane, P - 1)] : 0.f;
         acc = wave_sum(acc);
