@@ -247,7 +247,7 @@ extern "C" int denet_confmat_fused(const float* logits, const int64_t* label_tru
                                    int64_t w, int64_t H, int64_t W, int64_t* mat, void* stream) {
     if (!logits || !label_true || !mat) return DENET_E_BADARG;
     if (!pos(N) || !pos(K) || !pos(h) || !pos(w) || !pos(H) || !pos(W) || !pos(H * W)) return DENET_E_BADARG;
-    if (K > 128 || N > 65535) return DENET_E_UNSUPPORTED;
+    if (K > 128 || N > 65535 || H < h || W < w) return DENET_E_UNSUPPORTED;     // up-sampling only
     const size_t lds = (size_t)2 * K * w * 4 + (size_t)K * K * 4 + 128;
     if (lds > 160 * 1024) return DENET_E_UNSUPPORTED;
     if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(fused_metric_kernel<false>), lds))
@@ -263,7 +263,7 @@ extern "C" int denet_binary_iou_counts_fused(const float* logits2, const int64_t
                                              int64_t w, int64_t H, int64_t W, int64_t* counts, void* stream) {
     if (!logits2 || !label_true || !counts) return DENET_E_BADARG;
     if (!pos(N) || !pos(h) || !pos(w) || !pos(H) || !pos(W) || !pos(H * W)) return DENET_E_BADARG;
-    if (N > 65535) return DENET_E_UNSUPPORTED;
+    if (N > 65535 || H < h || W < w) return DENET_E_UNSUPPORTED;                 // up-sampling only
     const size_t lds = (size_t)2 * 2 * w * 4 + 128;
     hipLaunchKernelGGL(fused_metric_kernel<true>, dim3((unsigned)h, (unsigned)N), dim3(MT_THREADS), lds,
                        (hipStream_t)stream, logits2, label_true, 2, (int)h, (int)w, (int)H, (int)W,

@@ -103,6 +103,9 @@ static int max_span(int in_size, int out_size) {      // widest set of dst indic
 }
 
 static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g) {
+    // up-sampling only, as the reference (loss/losses.py:29-37 raises otherwise): every low-res row and
+    // column then owns at least one label row / column, which the kernel's band arithmetic relies on
+    if (H < h || W < w) return false;
     const int rows_max = max_span(h, H), emax = max_span(w, W);
     const float sx = bilinear_scale(w, W);
     // aim at ~256 phase-1 items (rows x cells x 2 halves) per 256-thread block

@@ -39,6 +39,11 @@ def test_workspace_queries_are_pure_host_calls():
     assert _lib.query("denet_head_step_workspace", 8, 1, 5, 21, 256, 41, 41, 321, 321) > 0
     assert _lib.query("denet_head_step_workspace", 0, 1, 5, 21, 256, 41, 41, 321, 321) < 0
     assert _lib.query("denet_upsample_loss_parts", 21, 41, 41, 321, 321, 1) % 41 == 0
+    # up-sampling only, as the reference (loss/losses.py:29-37): label maps smaller than the logits are refused
+    assert _lib.query("denet_upsample_loss_parts", 21, 41, 41, 40, 321, 1) < 0
+    assert _lib.query("denet_upsample_loss_parts", 21, 41, 41, 321, 40, 0) < 0
+    assert _lib.query("denet_head_step_workspace", 8, 1, 5, 21, 256, 41, 41, 33, 33) < 0
+    assert _lib.query("denet_upsample_loss_parts", 21, 41, 41, 41, 41, 1) > 0          # same size is fine
 
 
 def test_cpu_tensor_is_rejected_loudly():

@@ -241,7 +241,7 @@ def test_engine_deferred_losses_match_eager(name, dev):
         assert rel_err(eng.grads[k].cpu(), z["grad:" + k]) < TOL, k
 
 
-@pytest.mark.parametrize("geom", [(9, 9, 65, 65), (5, 13, 33, 97), (6, 7, 41, 50)])
+@pytest.mark.parametrize("geom", [(9, 9, 65, 65), (5, 13, 33, 97), (6, 7, 41, 50), (7, 9, 7, 9), (4, 5, 7, 5)])
 def test_loss_kernel_extreme_logits(geom, dev):
     """Logit swings of hundreds of nats between neighbouring positions: every exponential of a pixel
     underflows against the blended bound (exact-max fallback), and on power-of-two scales (the first two
