@@ -86,7 +86,7 @@ struct LossArgs {
 // moves by more than 100 octaves per cell (a first element that underflows must not hide a later one
 // that matters) and pixels whose exponentials all underflow take the generic arithmetic, and a block that
 // met either runs the generic gradient pass.
-template <int MODE, bool GRAD, int NCM = 0, bool UNI = false>
+template <int MODE, bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
 __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int bx, float* sm) {
     const float* __restrict__ logits = g.logits;
     const int64_t* __restrict__ Y = g.Y;
@@ -112,13 +112,14 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     float* lg0 = sm;                                      // [K][ncmax]  row py * log2e, columns cell_lo..
     float* lg1 = lg0 + kc;                                // [K][ncmax]  row py1 * log2e
     float* gl0 = lg1 + kc;                                // GRAD: [2 row halves][K][ncmax] left tap, row-tap 0
-    float* gl1 = gl0 + (GRAD ? 2 * kc : 0);
-    float* gr0 = gl1 + (GRAD ? 2 * kc : 0);
-    float* gr1 = gr0 + (GRAD ? 2 * kc : 0);
-    float* wg = gr1 + (GRAD ? 2 * kc : 0);                // [K]
+    constexpr int rsplit = GRAD ? RS : 0;                 // row groups of the gradient pass (2, or 1 for many classes)
+    float* gl1 = gl0 + rsplit * kc;
+    float* gr0 = gl1 + rsplit * kc;
+    float* gr1 = gr0 + rsplit * kc;
+    float* wg = gr1 + rsplit * kc;                        // [K]
     float* red = wg + K;                                  // [8]
     float* w1t = red + 8;                                 // [xw_max] horizontal lerp weight of each label column
-    int off = (2 + (GRAD ? 8 : 0)) * kc + K + 8 + xw_max;
+    int off = (2 + 4 * rsplit) * kc + K + 8 + xw_max;
     int* xs = reinterpret_cast<int*>(sm + off);           // [ncmax+1] first pixel of each cell
     off = (off + ncmax + 2 + 1) & ~1;
     f32x2* stats = reinterpret_cast<f32x2*>(sm + off);    // [rows_max][emax][ncmax] (shift, weight/sumexp), GRAD
@@ -330,10 +331,10 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     STAMP(4);
 
     // ---------------- phase 2 ----------------
-    const int rmid = (rows + 1) >> 1;
+    const int rmid = rsplit == 2 ? (rows + 1) >> 1 : rows;
     const bool fastp = UNI && slowf[0] == 0;
     const float dwv = g.dw;
-    for (int item = tid; item < K * ncell * 2; item += UL_T) {
+    for (int item = tid; item < K * ncell * rsplit; item += UL_T) {
         const int rh = item / (K * ncell);
         const int kcx = item - rh * (K * ncell);
         const int k = kcx / ncell, cl = kcx - k * ncell;
@@ -399,9 +400,11 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
         for (int idx = tid; idx < K * nown; idx += UL_T) {
             const int k = idx / nown, x = c0 + idx - k * nown;
             const int o = k * ncmax + (x - cell_lo);
-            float g0 = gl0[o] + gl0[kc + o], g1 = gl1[o] + gl1[kc + o];
-            if (x >= 1) { g0 += gr0[o - 1] + gr0[kc + o - 1]; g1 += gr1[o - 1] + gr1[kc + o - 1]; }
-            if (x == w - 1) { g0 += gr0[o] + gr0[kc + o]; g1 += gr1[o] + gr1[kc + o]; }
+            // second row group (absent with rsplit == 1: its sums count as zero)
+            auto two = [&](const float* arr, int i) { return rsplit == 2 ? arr[i] + arr[kc + i] : arr[i]; };
+            float g0 = two(gl0, o), g1 = two(gl1, o);
+            if (x >= 1) { g0 += two(gr0, o - 1); g1 += two(gr1, o - 1); }
+            if (x == w - 1) { g0 += two(gr0, o); g1 += two(gr1, o); }
             // undo nothing: g is d(loss)/d(logit) already (the log2e factors cancel: p is a probability)
             if (py1 == py) {
                 da[((int64_t)k * h + py) * w + x] = g0 + g1;
@@ -415,10 +418,10 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     STAMP(6);
 }
 
-template <int MODE, bool GRAD, int NCM = 0, bool UNI = false>
+template <int MODE, bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
 __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    upsample_loss_body<MODE, GRAD, NCM, UNI>(g, blockIdx.y, blockIdx.x, sm);
+    upsample_loss_body<MODE, GRAD, NCM, UNI, RS>(g, blockIdx.y, blockIdx.x, sm);
 }
 
 // Weighted CE (blockIdx.y < N0) and binary focal (the rest) in ONE launch: the two losses read
@@ -428,12 +431,12 @@ __global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
 // focal blocks run in the fifth slot and in the slots CE blocks free.  Measured slower: the focal
 // tiles inside the CE blocks (42 us), 6 or 8 waves per SIMD by capping registers (spills), four row
 // groups in phase 2 (LDS then limits a CU to 4 blocks), a cell-level soft-max shift in phase 1.
-template <bool GRAD, int NCM = 0, bool UNI = false>
+template <bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
 __global__ __launch_bounds__(UL_T) void upsample_loss_pair_kernel(LossArgs g0, LossArgs g1, int N0, int nb0, int nb1) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BSTAMP(0);
     if ((int)blockIdx.y < N0) {
-        if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD, NCM, UNI>(g0, blockIdx.y, blockIdx.x, sm);
+        if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD, NCM, UNI, RS>(g0, blockIdx.y, blockIdx.x, sm);
     } else {
         if ((int)blockIdx.x < nb1) upsample_loss_body<1, false>(g1, blockIdx.y - N0, blockIdx.x, sm);
     }

@@ -87,7 +87,7 @@ static int set_lds(KernelT kern, size_t lds) {
 
 // Launch geometry of upsample_loss_kernel, from the exact index rule (same float ops as the device).
 struct LossGeom {
-    int xsplit, rows_max, emax, xw_max, threads, ncmax;
+    int xsplit, rows_max, emax, xw_max, threads, ncmax, rsplit;
     size_t lds;
 };
 
@@ -123,7 +123,11 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
             const int span = first_dst_ge(c1, sx, w, W) - first_dst_ge(lo, sx, w, W);
             if (span > xw_max) xw_max = span;
         }
-        size_t off = (size_t)(2 + (grad ? 8 : 0)) * K * ncmax + K + 8 + xw_max;
+        // gradient pass items: (class, cell) x row groups.  Two row groups give K = 21 enough items for 256
+        // threads; from ~500 (class, cell) pairs on, one group is enough and halves the accumulator arrays
+        // (K = 81: 62 -> 41 KB of LDS, three blocks per CU instead of two)
+        const int rsplit = grad ? (K * (cwe + 1) >= 512 ? 1 : 2) : 0;
+        size_t off = (size_t)(2 + 4 * rsplit) * K * ncmax + K + 8 + xw_max;
         off = (off + ncmax + 2 + 1) & ~(size_t)1;
         off += grad ? (size_t)2 * rows_max * emax * ncmax : 0;
         off += grad ? (size_t)2 * rows_max * ncmax + 2 : 0;   // per-(row, cell) shift pair + the fast-path flag
@@ -132,6 +136,7 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         if (lds <= 64 * 1024 || (cw == 1 && lds <= 150 * 1024)) {
             g->xsplit = xsplit; g->rows_max = rows_max; g->emax = emax; g->xw_max = xw_max; g->threads = UL_T;
             g->ncmax = ncmax;
+            g->rsplit = rsplit;
             g->lds = lds;
             found = true;
             break;
@@ -180,15 +185,22 @@ static int launch_loss(int mode, bool grad, const float* logits, const int64_t* 
     }
     if (mode == 0) {
         if (grad) {
-            if (g.ncmax == 16 && dw > 0.f) {
-                int rc = set_lds(upsample_loss_kernel<0, true, 16, true>, g.lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL((upsample_loss_kernel<0, true, 16, true>), grid, block, g.lds, st, a);
-            } else if (dw > 0.f) {
-                int rc = set_lds(upsample_loss_kernel<0, true, 0, true>, g.lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL((upsample_loss_kernel<0, true, 0, true>), grid, block, g.lds, st, a);
-            } else if (g.ncmax == 16) UL_GO3(0, true, 16) else UL_GO(0, true)
+            // instantiation: LDS stride constant (NCM 16 / run time), uniform-step arithmetic, row groups
+#define UL_GRAD(NC, U, RSV)                                                                                  \
+    {                                                                                                        \
+        int rc = set_lds(upsample_loss_kernel<0, true, NC, U, RSV>, g.lds);                                  \
+        if (rc) return rc;                                                                                   \
+        hipLaunchKernelGGL((upsample_loss_kernel<0, true, NC, U, RSV>), grid, block, g.lds, st, a);          \
+    }
+            const bool n16 = g.ncmax == 16, uni = dw > 0.f;
+            if (g.rsplit == 2) {
+                if (n16 && uni) UL_GRAD(16, true, 2) else if (uni) UL_GRAD(0, true, 2)
+                else if (n16) UL_GRAD(16, false, 2) else UL_GRAD(0, false, 2)
+            } else {
+                if (n16 && uni) UL_GRAD(16, true, 1) else if (uni) UL_GRAD(0, true, 1)
+                else if (n16) UL_GRAD(16, false, 1) else UL_GRAD(0, false, 1)
+            }
+#undef UL_GRAD
         } else UL_GO(0, false)
     } else {
         UL_GO(1, false)
@@ -218,27 +230,22 @@ int denet_loss_pair_fwd(const float* logits, const int64_t* Yq_full, const float
                 g1.xw_max, alpha, gamma, part_p, nullptr, nullptr, 0.f};
     dim3 grid((unsigned)(nb0 > nb1 ? nb0 : nb1), (unsigned)(N + NB)), block(UL_T);
     hipStream_t st = (hipStream_t)stream;
-    if (grad && dw > 0.f && g0.ncmax == 16) {
-        int rc = set_lds(upsample_loss_pair_kernel<true, 16, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 16, true>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
-    } else if (grad && dw > 0.f) {
-        int rc = set_lds(upsample_loss_pair_kernel<true, 0, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 0, true>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
-    } else if (grad && g0.ncmax == 16) {
-        int rc = set_lds(upsample_loss_pair_kernel<true, 16>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((upsample_loss_pair_kernel<true, 16>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
-    } else if (grad) {
-        int rc = set_lds(upsample_loss_pair_kernel<true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(upsample_loss_pair_kernel<true>, grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
-    } else {
-        int rc = set_lds(upsample_loss_pair_kernel<false>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(upsample_loss_pair_kernel<false>, grid, block, lds, st, a0, a1, (int)N, nb0, nb1);
+#define UL_PAIR(...)                                                                                         \
+    {                                                                                                        \
+        int rc = set_lds(upsample_loss_pair_kernel<__VA_ARGS__>, lds);                                       \
+        if (rc) return rc;                                                                                   \
+        hipLaunchKernelGGL((upsample_loss_pair_kernel<__VA_ARGS__>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1); \
     }
+    const bool n16 = g0.ncmax == 16, uni = dw > 0.f;
+    if (!grad) UL_PAIR(false)
+    else if (g0.rsplit == 2) {
+        if (n16 && uni) UL_PAIR(true, 16, true, 2) else if (uni) UL_PAIR(true, 0, true, 2)
+        else if (n16) UL_PAIR(true, 16, false, 2) else UL_PAIR(true, 0, false, 2)
+    } else {
+        if (n16 && uni) UL_PAIR(true, 16, true, 1) else if (uni) UL_PAIR(true, 0, true, 1)
+        else if (n16) UL_PAIR(true, 16, false, 1) else UL_PAIR(true, 0, false, 1)
+    }
+#undef UL_PAIR
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
