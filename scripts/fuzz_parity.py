@@ -42,11 +42,20 @@ def sweep(seed=0, count=24, verbose=True):
         Fq = ep["Fq"].to(dev).requires_grad_(True)
         Fs = ep["Fs"].to(dev).requires_grad_(True)
         lab = ep["label"].reshape(s.N, s.way).to(dev)
+        # train mode in half of the cases: injected dropout multipliers (keep-prob 0.5, scale 2), the
+        # same on both sides (model/common.py:231,326)
+        gm = wm = None
+        if rng.random() < 0.5:
+            tg = torch.Generator().manual_seed(9000 + it)
+            gm = 2.0 * torch.bernoulli(torch.full((s.N * s.way * s.shot, s.c), 0.5), generator=tg)
+            wm = 2.0 * torch.bernoulli(torch.full((s.N, s.K, s.c), 0.5), generator=tg)
         lk, lp, logits, binl = ops.HeadStepFunction.apply(
-            Fq, Fs, *P, ep["Ys"].to(dev), lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+            Fq, Fs, *P, ep["Ys"].to(dev), lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev), ep["wgt"].to(dev),
+            None if gm is None else gm.to(dev), None if wm is None else wm.to(dev))
         lk.backward()
         torch.cuda.synchronize()
-        ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+        ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state,
+                              None if gm is None else gm.reshape(-1, s.c, 1, 1), wm)
         errs = {"logits_full": rel_err(logits.cpu(), ref["logits_full"]), "logits_binary": rel_err(binl.cpu(), ref["logits_binary"]),
                 "loss_k": rel_err(lk.detach().cpu(), ref["loss_k"]), "loss_p": rel_err(lp.cpu(), ref["loss_p"]),
                 "dFq": rel_err(Fq.grad.float().cpu(), ref["dFq"]), "dFs": rel_err(Fs.grad.float().cpu(), ref["dFs"])}
@@ -58,7 +67,7 @@ def sweep(seed=0, count=24, verbose=True):
         if bad:
             failures.append((s, bad))
         if verbose:
-          print(f"{it:3d} N={s.N} way={s.way} shot={s.shot} K={s.K} c={s.c} {h}x{w}->{H}x{W} {s.feat_dtype} max={max(errs.values()):.2e}"
+          print(f"{it:3d} N={s.N} way={s.way} shot={s.shot} K={s.K} c={s.c} {h}x{w}->{H}x{W} {s.feat_dtype}{' masks' if gm is not None else ''} max={max(errs.values()):.2e}"
               + (f"  FAIL {bad}" if bad else ""), flush=True)
         for k, v in errs.items():
             if lim[k] == 1e-3:
