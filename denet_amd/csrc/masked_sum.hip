@@ -117,6 +117,15 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
     size_t lds = (size_t)P * 4 + 32 + 64 + (W1 ? 256 * 64 : 0);
+    // The in-kernel gather touches one 64-byte sector of the label map per mask element, once per channel
+    // block: C/16 times 64 P bytes per image against C P sF bytes of features.  At 41 x 41 that is cheaper
+    // than a launch of its own; from P = 4096 on (81 x 81: 420 KB of sectors per block against 210 KB of bf16
+    // features) the mask is resized once per image first and the blocks read it back as P floats.
+    if (P >= 4096) {
+        int rc = denet_mask_resize(Ys, B, H, W, h, w, mask, cnt, stream);
+        if (rc) return rc;
+        Ys = nullptr;
+    }
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
                            (const float*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w,
