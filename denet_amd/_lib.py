@@ -17,33 +17,35 @@ LIB_PATH = os.environ.get("DENET_HIP_LIB") or os.path.join(_HERE, "libdenet_hip.
 F32, BF16 = 0, 1
 BWD_HAVE_FOCAL, BWD_NO_DFS, BWD_ONLY_DFS = 1, 2, 4      # denet_head_step_bwd flags (include/denet_hip.h)
 
-# signature table: p = device pointer (tensor / None), l = int64, i = int, f = float,
-# h = host pointer (ctypes object / None)
+# signature table: p = device pointer of any dtype (features, workspace; tensor / None),
+# F = device pointer to float32, L = device pointer to int64 (both checked against the tensor's dtype:
+# the kernels read raw memory, so a bf16 / half / int32 tensor would be misread without an error),
+# l = int64, i = int, f = float, h = host pointer (ctypes object / None)
 # the trailing stream argument is appended automatically ("s").
 _SIGS = {
-    "denet_mask_resize": "plllllpp",
-    "denet_masked_sum_fwd": "piplllp",
-    "denet_masked_sum_bwd": "pplllpi",
-    "denet_masked_pool_fwd": "pip" "llllll" "ppp",
-    "denet_proto_extend_fwd": "pppppppppppp" "llllll" "ppppp",
-    "denet_proto_extend_bwd": "pl" "ppppp" "ppp" "ppp" "llllll" "pppppppp" "pl",
-    "denet_classify_fwd": "pipp" "lllll" "i" "pp",
-    "denet_classify_shared_fwd": "pip" "llll" "p",
-    "denet_classify_bwd": "pip" "pppp" "llll" "pp",
-    "denet_binary_logits": "pp" "llll" "i" "p",
-    "denet_batch_mean": "p" "ll" "p",
-    "denet_sum_parts": "p" "lll" "p",
-    "denet_upsample_wce_fwd": "ppp" "llllll" "ppp",
-    "denet_upsample_focal_fwd": "pp" "lllll" "ff" "p",
-    "denet_loss_finalize": "pp" "llll" "i" "ppp",
-    "denet_combine_slabs": "pppp" "ll" "p",
-    "denet_upsample_bilinear": "p" "lllll" "p",
-    "denet_confmat": "pp" "lll" "p",
-    "denet_confmat_fused": "pp" "llllll" "p",
-    "denet_binary_iou_counts": "pp" "ll" "p",
-    "denet_binary_iou_counts_fused": "pp" "lllll" "p",
-    "denet_head_step_fwd": "ppi" "ppppp" "ppppppp" "pp" "lllllllll" "i" "ppp" "pl" "h",
-    "denet_head_step_bwd": "pip" "ppp" "pp" "p" "lllllllll" "pp" "ppppppp" "pi" "pl" "h",
+    "denet_mask_resize": "L" "lllll" "FF",
+    "denet_masked_sum_fwd": "piF" "lll" "F",
+    "denet_masked_sum_bwd": "FF" "lll" "pi",
+    "denet_masked_pool_fwd": "piL" "llllll" "FFF",
+    "denet_proto_extend_fwd": "FFFFFFFFF" "L" "FF" "llllll" "FFFFF",
+    "denet_proto_extend_bwd": "Fl" "FFFFF" "FFF" "LFF" "llllll" "FFFFFFFF" "pl",
+    "denet_classify_fwd": "piFL" "lllll" "i" "FF",
+    "denet_classify_shared_fwd": "piF" "llll" "F",
+    "denet_classify_bwd": "piF" "FFFF" "llll" "pF",
+    "denet_binary_logits": "FL" "llll" "i" "F",
+    "denet_batch_mean": "F" "ll" "F",
+    "denet_sum_parts": "F" "lll" "F",
+    "denet_upsample_wce_fwd": "FLF" "llllll" "FFF",
+    "denet_upsample_focal_fwd": "FL" "lllll" "ff" "F",
+    "denet_loss_finalize": "FF" "llll" "i" "FFF",
+    "denet_combine_slabs": "FFFF" "ll" "F",
+    "denet_upsample_bilinear": "F" "lllll" "F",
+    "denet_confmat": "FL" "lll" "L",
+    "denet_confmat_fused": "FL" "llllll" "L",
+    "denet_binary_iou_counts": "FL" "ll" "L",
+    "denet_binary_iou_counts_fused": "FL" "lllll" "L",
+    "denet_head_step_fwd": "ppi" "LLLLF" "FFFFFFF" "FF" "lllllllll" "i" "FFF" "pl" "h",
+    "denet_head_step_bwd": "piL" "FFF" "FF" "F" "lllllllll" "pp" "FFFFFFF" "Fi" "pl" "h",
 }
 _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
@@ -53,7 +55,7 @@ _NOSTREAM = {
     "denet_head_step_workspace": (ctypes.c_int64, "lllllllll"),
     "denet_upsample_loss_parts": (ctypes.c_int64, "llllli"),
 }
-_CT = {"p": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
+_CT = {"p": ctypes.c_void_p, "F": ctypes.c_void_p, "L": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
 
 
 class Probe(ctypes.Structure):
@@ -98,10 +100,17 @@ def load():
     return lib
 
 
-def _ptr(x):
+_WANT = {"F": torch.float32, "L": torch.int64}
+
+
+def _ptr(x, code="p", where=""):
     if x is None:
         return None
     if isinstance(x, torch.Tensor):
+        want = _WANT.get(code)
+        if want is not None and x.dtype != want:
+            raise DenetHipError(f"{where}: expected a {want} tensor, got {x.dtype} "
+                                "(the kernels read raw memory; cast explicitly)")
         if not x.is_cuda:
             raise DenetHipError("denet_amd ops need device tensors (got a CPU tensor); there is no CPU path")
         if not x.is_contiguous():
@@ -117,19 +126,7 @@ def strerror(code: int) -> str:
 def call(name: str, *args):
     """Enqueue `name` on torch's current stream; raise on a non-zero code."""
     lib = load()
-    sig = _SIGS[name]
-    if len(args) != len(sig):
-        raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
-    conv = []
-    for c, a in zip(sig, args):
-        if c == "p":
-            conv.append(_ptr(a))
-        elif c == "h":
-            conv.append(None if a is None else ctypes.cast(ctypes.pointer(a), ctypes.c_void_p))
-        elif c == "f":
-            conv.append(float(a))
-        else:
-            conv.append(int(a))
+    conv = _convert(name, args)
     stream = torch.cuda.current_stream().cuda_stream
     rc = getattr(lib, name)(*conv, stream)
     if rc != 0:
@@ -141,9 +138,9 @@ def _convert(name, args):
     if len(args) != len(sig):
         raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
     conv = []
-    for c, a in zip(sig, args):
-        if c == "p":
-            conv.append(_ptr(a))
+    for i, (c, a) in enumerate(zip(sig, args)):
+        if c in "pFL":
+            conv.append(_ptr(a, c, f"{name} argument {i}"))
         elif c == "h":
             conv.append(None if a is None else ctypes.cast(ctypes.pointer(a), ctypes.c_void_p))
         elif c == "f":
@@ -175,7 +172,12 @@ def query(name: str, *args) -> int:
     return int(getattr(load(), name)(*[int(a) for a in args]))
 
 
-def feat_code(t: torch.Tensor) -> int:
+def feat_code(t: torch.Tensor, *same) -> int:
+    """DENET_F32 / DENET_BF16 for feature tensor `t`; every tensor in `same` (the other feature
+    tensors of the call: one code describes them all) must have the same dtype."""
+    for o in same:
+        if o is not None and o.dtype != t.dtype:
+            raise DenetHipError(f"feature tensors of one call must share a dtype, got {t.dtype} and {o.dtype}")
     if t.dtype == torch.float32:
         return F32
     if t.dtype == torch.bfloat16:

@@ -78,14 +78,14 @@ class HeadStepEngine:
         deferred = Yq_full is not None
         have_focal = Yq is not None
         g = self.grads
-        fwd = _lib.bind("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask,
+        fwd = _lib.bind("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask,
                         weight_mask, N, way, shot, K, C, h, w, H, W,
                         _lib.GRAD_DEFER_LOSSES if deferred else 1, self.logits_full, self.logits_binary,
                         self.losses, self.ws, self.ws_bytes, self._probe)
         bwd = {}
         for phase, fl in ((0, 0), (1, _lib.BWD_NO_DFS), (2, _lib.BWD_ONLY_DFS)):
             bwd[phase] = _lib.bind(
-                "denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
+                "denet_head_step_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels, params["gam.gate.0.weight"],
                 params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
                 N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
                 g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
@@ -109,7 +109,7 @@ class HeadStepEngine:
         self._deferred = bool(defer_losses and with_grad and Yq_full is not None)
         self._have_focal = Yq is not None
         mode = _lib.GRAD_DEFER_LOSSES if self._deferred else (1 if with_grad else 0)
-        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask, weight_mask,
+        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask, weight_mask,
              N, way, shot, K, C, h, w, H, W, mode, self.logits_full, self.logits_binary,
              self.losses, self.ws, self.ws_bytes, self._probe)
 
@@ -120,7 +120,7 @@ class HeadStepEngine:
         N, way, shot, K, C, h, w, H, W = self.dims
         g = self.grads
         flags = (_lib.BWD_HAVE_FOCAL if self._have_focal else 0) | {0: 0, 1: _lib.BWD_NO_DFS, 2: _lib.BWD_ONLY_DFS}[phase]
-        call("denet_head_step_bwd", Fq, feat_code(Fq), labels, params["gam.gate.0.weight"],
+        call("denet_head_step_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels, params["gam.gate.0.weight"],
              params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
              N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
              g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],

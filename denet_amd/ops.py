@@ -426,7 +426,7 @@ class HeadStepFunction(torch.autograd.Function):
         logits = _f32(N, K, h, w, device=dev)
         binl = _f32(N * way, 2, h, w, device=dev)
         losses = torch.zeros(2, dtype=torch.float32, device=dev)
-        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq), Ys, labels, Yq, Yq_full, wgt, *params,
+        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *params,
              gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
              ws, nbytes, None)
         ctx.dims = (N, way, shot, K, C, h, w, H, W)
@@ -458,7 +458,7 @@ class HeadStepFunction(torch.autograd.Function):
         dW1, dW2, dWl = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wl)
         db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
         g = g_k.contiguous().float().reshape(1)
-        call("denet_head_step_bwd", Fq, feat_code(Fq), labels, W1, W2, Wl, gate_mask, weight_mask, g,
+        call("denet_head_step_bwd", Fq, feat_code(Fq, dFq, dFs), labels, W1, W2, Wl, gate_mask, weight_mask, g,
              N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, None,
              1 if ctx.have_focal else 0, ctx.ws, ctx.ws.numel(), None)
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7

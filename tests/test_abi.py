@@ -51,3 +51,18 @@ def test_cpu_tensor_is_rejected_loudly():
     from denet_amd import ops, _lib
     with pytest.raises(_lib.DenetHipError):
         ops.mask_resize(torch.zeros(1, 4, 4, dtype=torch.int64), 2, 2)
+
+
+def test_wrong_dtype_is_rejected_before_any_launch():
+    """The kernels read raw memory: a bf16 / half / int32 tensor where float32 / int64 is expected, or
+    Fq and Fs of different dtypes under one dtype code, must raise instead of being misread."""
+    import torch
+    from denet_amd import _lib
+    with pytest.raises(_lib.DenetHipError, match="float32"):
+        _lib._convert("denet_batch_mean", (torch.zeros(2, 4, dtype=torch.bfloat16), 2, 4, torch.zeros(4)))
+    with pytest.raises(_lib.DenetHipError, match="int64"):
+        _lib._convert("denet_mask_resize", (torch.zeros(1, 4, 4, dtype=torch.int32), 1, 4, 4, 2, 2,
+                                            torch.zeros(1, 4), torch.zeros(1)))
+    with pytest.raises(_lib.DenetHipError, match="share a dtype"):
+        _lib.feat_code(torch.zeros(1), torch.zeros(1, dtype=torch.bfloat16))
+    assert _lib.feat_code(torch.zeros(1, dtype=torch.bfloat16), torch.zeros(2, dtype=torch.bfloat16)) == _lib.BF16
