@@ -7,16 +7,31 @@
 #define UL_CH 4
 #define UL_IGNORE 255
 
-// smallest q in [0, out_size] with min(int(scale*q), in_size-1) >= target
+// smallest q in [0, out_size] with min(int(scale*q), in_size-1) >= target: the first destination index whose
+// upper bilinear tap is `target` or beyond.  The predicate is monotone in q, so a closed-form candidate plus
+// a fix-up with the exact predicate (the float ops ATen uses) gives the same answer as a search.
 __host__ __device__ __forceinline__ int first_dst_ge(int target, float scale, int in_size, int out_size) {
-    int lo = 0, hi = out_size;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        int i0 = (int)(scale * (float)mid);
-        if (i0 > in_size - 1) i0 = in_size - 1;
-        if (i0 >= target) hi = mid; else lo = mid + 1;
+    if (target <= 0) return 0;
+    if (target > in_size - 1 || !(scale > 0.f)) return out_size;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float qf = ceilf((float)target * __builtin_amdgcn_rcpf(scale));     // candidate only: fixed up below
+#else
+    const float qf = ceilf((float)target / scale);
+#endif
+    int q = qf < (float)out_size ? (int)qf : out_size;
+    // the candidate is the answer unless target/scale sits within a rounding of an integer: verify it with the
+    // exact predicate (two evaluations) and search only if that fails
+    const bool low_ok = q == 0 || (int)(scale * (float)(q - 1)) < target;
+    const bool high_ok = q == out_size || (int)(scale * (float)q) >= target;
+    if (!(low_ok && high_ok)) {
+        int lo = 0, hi = out_size;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)(scale * (float)mid) >= target) hi = mid; else lo = mid + 1;
+        }
+        q = lo;
     }
-    return lo;
+    return q;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
@@ -38,8 +53,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// MODE 0: weighted CE (loss/losses.py:19-44 with per-episode class weights, trainer/utils.py:270-277)
-// MODE 1: binary focal (loss/losses.py:47-79)
+// Weighted CE (loss/losses.py:19-44 with per-episode class weights, trainer/utils.py:270-277), exact form.
+// (The binary focal loss, loss/losses.py:47-79, has a body of its own: focal_body, dev_wce_chain.hpp.)
 //
 // Block = (episode n, low-res row py, column range [c0,c1) of the low-res grid), 256 threads.
 // All soft-max arithmetic is done in the log2 domain (the logit rows are multiplied by log2(e) when
@@ -66,34 +81,23 @@ struct LossArgs {
     int K, h, w, H, W, xsplit, rows_max, emax, xw_max;
     float alpha, gamma;
     float *part, *dlog_a, *dlog_b;
-    float dw;            // UNI kernels: the step of the horizontal lerp weight between neighbouring label columns
+    int kchunk;          // chain kernels (dev_wce_chain.hpp): classes per table chunk
+    float sy, sx;        // bilinear_scale(h, H), bilinear_scale(w, W), computed once on the host
 };
 
 // Body for block (episode n, bx = py * xsplit + xsid); 256 threads; sm: the geometry's LDS bytes.
-// NCM > 0: the LDS row stride (cells + taps) as a compile-time constant -- the launcher picks the
-// instantiation that matches the geometry.  Every LDS address of the two inner loops is then a base
-// register plus an immediate offset instead of a v_add per access (8 of 52 issue slots per four
-// pixel-classes in the gradient pass: 34.4 -> 33.4 us).  NCM = 0: run-time stride.  (The class count as
-// a constant as well, K = 21 fully unrolled, measured slower: 36.3 us.)
-//
-// UNI (weighted CE with gradient only): the launcher has verified, with the device's own float
-// arithmetic, that inside every cell the horizontal lerp weights of consecutive label columns are an
-// exact arithmetic progression with step g.dw (true whenever (w-1)/(W-1) is a power of two: 41 -> 321).
-// The shifted exponent of a class is linear in that weight, so along a cell row
-//   exp2(x[e+1] - U[e+1]) = exp2(x[e] - U[e]) * rho,   rho = exp2((d - dM) * dw)
-// and one multiplication replaces fma + sub + v_exp_f32 (a quarter-rate instruction) per pixel-class in
-// both phases; two exponentials per (row, cell half, class) start the chain.  Chains whose exponent
-// moves by more than 100 octaves per cell (a first element that underflows must not hide a later one
-// that matters) and pixels whose exponentials all underflow take the generic arithmetic, and a block that
-// met either runs the generic gradient pass.
-template <int MODE, bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
+// This is the EXACT form: one exponential per (pixel, class) in either phase, the lerp weights exactly as
+// ATen rounds them.  The weighted CE normally runs on the chain kernels of dev_wce_chain.hpp, which call
+// this body for blocks whose logits leave their validity range and for geometries they do not cover
+// (cells of other widths than 8 or 9 label columns).
+// RS: row groups of the gradient pass (2 gives K = 21 enough (class, cell, group) items for 256 threads).
+template <bool GRAD, int RS = 2>
 __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int bx, float* sm) {
     const float* __restrict__ logits = g.logits;
     const int64_t* __restrict__ Y = g.Y;
     const float* __restrict__ wgt = g.wgt;
     const int K = g.K, h = g.h, w = g.w, H = g.H, W = g.W, xsplit = g.xsplit, rows_max = g.rows_max, emax = g.emax,
               xw_max = g.xw_max;
-    const float alpha = g.alpha, gamma = g.gamma;
     float* __restrict__ part = g.part;
     float* __restrict__ dlog_a = g.dlog_a;
     float* __restrict__ dlog_b = g.dlog_b;
@@ -104,7 +108,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     const int c0 = xsid * cw, c1 = min(w, c0 + cw);
     const int cell_lo = (GRAD && c0 > 0) ? c0 - 1 : c0;
     const int ncell = c1 - cell_lo;                       // cells processed
-    const int ncmax = NCM > 0 ? NCM : cw + (GRAD ? 2 : 1);   // LDS stride: cells + right tap (+ left halo cell)
+    const int ncmax = cw + (GRAD ? 2 : 1);            // LDS stride: cells + right tap (+ left halo cell)
     const int col_hi = min(c1, w - 1);                    // last logits column needed
     const int ncol = col_hi - cell_lo + 1;
 
@@ -124,13 +128,9 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
     off = (off + ncmax + 2 + 1) & ~1;
     f32x2* stats = reinterpret_cast<f32x2*>(sm + off);    // [rows_max][emax][ncmax] (shift, weight/sumexp), GRAD
     off += GRAD ? 2 * rows_max * emax * ncmax : 0;
-    f32x2* mst = reinterpret_cast<f32x2*>(sm + off);      // [rows_max][ncmax] (Ma, Mb - Ma) of each (row, cell), GRAD
-    off += GRAD ? 2 * rows_max * ncmax : 0;
-    int* slowf = reinterpret_cast<int*>(sm + off);        // UNI: some item of the block left the fast arithmetic
-    off += GRAD ? 2 : 0;
     unsigned char* lab8 = reinterpret_cast<unsigned char*>(sm + off);   // [rows_max][xw_max]
 
-    const float sy = bilinear_scale(h, H), sx = bilinear_scale(w, W);
+    const float sy = g.sy, sx = g.sx;
     const int ys = first_dst_ge(py, sy, h, H), ye = first_dst_ge(py + 1, sy, h, H);
     const int rows = ye - ys;
 
@@ -153,8 +153,7 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             }
         }
     }
-    for (int k = tid; k < K; k += UL_T) wg[k] = (MODE == 0 && wgt) ? wgt[(int64_t)n * K + k] : 1.f;
-    if (UNI && tid == 0) slowf[0] = 0;
+    for (int k = tid; k < K; k += UL_T) wg[k] = wgt ? wgt[(int64_t)n * K + k] : 1.f;
     for (int c = tid; c <= ncell; c += UL_T) xs[c] = first_dst_ge(cell_lo + c, sx, w, W);
     __syncthreads();
     STAMP(1);
@@ -217,12 +216,6 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             Ma = fmaxf(Ma, h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl]);
             Mb = fmaxf(Mb, h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]);
         }
-        if (UNI && hf == 0) {
-            f32x2 m2;
-            m2[0] = Ma;
-            m2[1] = Mb - Ma;
-            mst[r * ncmax + cl] = m2;
-        }
         for (int x0 = xb; x0 < xe; x0 += UL_CH) {
             const int cntx = min(UL_CH, xe - x0);
             float w1[UL_CH], U[UL_CH], se[UL_CH];
@@ -236,36 +229,17 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
                 se[e] = 0.f;
             }
             bool under = false;
-            if constexpr (UNI) {
-                const float dM = Mb - Ma, dw = g.dw;
-                float dmax = 0.f;
 #pragma unroll 3
-                for (int k = 0; k < K; ++k) {
-                    const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
-                    const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
-                    const float a2 = a - Ma, d2 = d - dM;
-                    dmax = fmaxf(dmax, fabsf(d2));
-                    float E = __builtin_amdgcn_exp2f(fmaf(w1[0], d2, a2));
-                    const float rho = __builtin_amdgcn_exp2f(d2 * dw);
-                    se[0] += E;
+            for (int k = 0; k < K; ++k) {
+                const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
+                const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
 #pragma unroll
-                    for (int e = 1; e < UL_CH; ++e) { E *= rho; se[e] += E; }
-                }
-                under = !(dmax <= 100.f);
-            } else {
-#pragma unroll 3
-                for (int k = 0; k < K; ++k) {
-                    const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
-                    const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
-#pragma unroll
-                    for (int e = 0; e < UL_CH; ++e) se[e] += __builtin_amdgcn_exp2f(fmaf(w1[e], d, a) - U[e]);
-                }
+                for (int e = 0; e < UL_CH; ++e) se[e] += __builtin_amdgcn_exp2f(fmaf(w1[e], d, a) - U[e]);
             }
 #pragma unroll
             for (int e = 0; e < UL_CH; ++e) under = under || !(se[e] > 1e-30f);
             if (under) {
                 // exact per-pixel max (rare): every exponential underflowed against the bound
-                if constexpr (UNI) slowf[0] = 1;
 #pragma unroll
                 for (int e = 0; e < UL_CH; ++e) U[e] = -INFINITY;
                 for (int k = 0; k < K; ++k) {
@@ -291,22 +265,11 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
                     const float a = h0 * lg0[k * ncmax + cl] + h1 * lg1[k * ncmax + cl];
                     const float d = (h0 * lg0[k * ncmax + cr] + h1 * lg1[k * ncmax + cr]) - a;
                     const float vl = fmaf(w1[e], d, a);            // label logit * log2e
-                    if (MODE == 0) {
-                        const float wy = wg[k];
-                        ce = wy;
-                        if (owned) {
-                            num += wy * (((__log2f(se[e]) + U[e]) - vl) * UL_LN2);
-                            den += wy;
-                        }
-                    } else if (owned) {
-                        // log(softmax) as the reference computes it: -inf when the prob underflows
-                        const float p = __builtin_amdgcn_exp2f(vl - U[e]) / se[e];
-                        const float lp = logf(p);
-                        const float om = 1.f - p;
-                        const float mod = (gamma == 2.f) ? om * om : powf(om, gamma);
-                        const float ay = k == 1 ? 1.f - alpha : alpha;
-                        num -= ay * (mod * lp);
-                        den += ay;
+                    const float wy = wg[k];
+                    ce = wy;
+                    if (owned) {
+                        num += wy * (((__log2f(se[e]) + U[e]) - vl) * UL_LN2);
+                        den += wy;
                     }
                 }
                 if (GRAD && e < cntx) {
@@ -332,8 +295,6 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
 
     // ---------------- phase 2 ----------------
     const int rmid = rsplit == 2 ? (rows + 1) >> 1 : rows;
-    const bool fastp = UNI && slowf[0] == 0;
-    const float dwv = g.dw;
     for (int item = tid; item < K * ncell * rsplit; item += UL_T) {
         const int rh = item / (K * ncell);
         const int kcx = item - rh * (K * ncell);
@@ -355,34 +316,14 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
             float gS = 0.f, gB = 0.f;
             const f32x2* strow = stats + (r * emax) * ncmax + cl;
             const unsigned char* lrow = lab8 + r * xw_max + (x0 - xbase);
-            if (UNI && fastp) {
-                const f32x2 m2 = mst[r * ncmax + cl];
-                const float d2 = d - m2[1];
-                const float w1 = wrow[0];
-                float E = __builtin_amdgcn_exp2f(fmaf(w1, d2, a - m2[0]));
-                const float rho = __builtin_amdgcn_exp2f(d2 * dwv);
-                const float* srow = reinterpret_cast<const float*>(strow) + 1;
-                // sum_e w1[e] g[e] with w1[e] = w1[0] + e dw:  sum_e e g[e] = nx * gS - sum_e (g[0] + .. + g[e])
-                float pre = 0.f;
 #pragma unroll 4
-                for (int e = 0; e < nx; ++e) {
-                    float g = E * srow[e * 2 * ncmax];
-                    g -= ((int)lrow[e] == k) ? wk : 0.f;
-                    gS += g;
-                    pre += gS;
-                    E *= rho;
-                }
-                gB = fmaf(dwv, fmaf((float)nx, gS, -pre), w1 * gS);
-            } else {
-#pragma unroll 4
-                for (int e = 0; e < nx; ++e) {
-                    const float w1 = wrow[e];
-                    const f32x2 st = strow[e * ncmax];
-                    float g = __builtin_amdgcn_exp2f(fmaf(w1, d, a) - st[0]) * st[1];
-                    g -= ((int)lrow[e] == k) ? wk : 0.f;
-                    gS += g;
-                    gB += g * w1;
-                }
+            for (int e = 0; e < nx; ++e) {
+                const float w1 = wrow[e];
+                const f32x2 st = strow[e * ncmax];
+                float g = __builtin_amdgcn_exp2f(fmaf(w1, d, a) - st[0]) * st[1];
+                g -= ((int)lrow[e] == k) ? wk : 0.f;
+                gS += g;
+                gB += g * w1;
             }
             const float gA = gS - gB;                   // sum of g*(1-w1)
             L0 += h0 * gA; L1 += h1 * gA;
@@ -416,31 +357,6 @@ __device__ __forceinline__ void upsample_loss_body(const LossArgs& g, int n, int
         }
     }
     STAMP(6);
-}
-
-template <int MODE, bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
-__global__ __launch_bounds__(UL_T) void upsample_loss_kernel(LossArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    upsample_loss_body<MODE, GRAD, NCM, UNI, RS>(g, blockIdx.y, blockIdx.x, sm);
-}
-
-// Weighted CE (blockIdx.y < N0) and binary focal (the rest) in ONE launch: the two losses read
-// different logit tensors and label maps and are independent, so their blocks run side by side.
-// Per-block time stamps (scripts/diag/loss_stamps.hip, C2 batch 8): the kernel is bound by VALU issue;
-// the CE blocks fill 4 of the 5 slots a CU has at 85 VGPRs and finish 18-30 us after the launch, the
-// focal blocks run in the fifth slot and in the slots CE blocks free.  Measured slower: the focal
-// tiles inside the CE blocks (42 us), 6 or 8 waves per SIMD by capping registers (spills), four row
-// groups in phase 2 (LDS then limits a CU to 4 blocks), a cell-level soft-max shift in phase 1.
-template <bool GRAD, int NCM = 0, bool UNI = false, int RS = 2>
-__global__ __launch_bounds__(UL_T) void upsample_loss_pair_kernel(LossArgs g0, LossArgs g1, int N0, int nb0, int nb1) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    BSTAMP(0);
-    if ((int)blockIdx.y < N0) {
-        if ((int)blockIdx.x < nb0) upsample_loss_body<0, GRAD, NCM, UNI, RS>(g0, blockIdx.y, blockIdx.x, sm);
-    } else {
-        if ((int)blockIdx.x < nb1) upsample_loss_body<1, false>(g1, blockIdx.y - N0, blockIdx.x, sm);
-    }
-    BSTAMP(1);
 }
 
 // loss_k = mean_n num_n/den_n ; loss_p = sum num / sum den ; scale[n] = 1/(N*den_n)

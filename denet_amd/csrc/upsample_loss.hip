@@ -18,6 +18,7 @@
 #include "denet_common.hpp"
 
 #include "dev_upsample_loss.hpp"
+#include "dev_wce_chain.hpp"
 
 // out[n,i] = gmul * scale[n] * (a[n,i] + b[n,i])   (dense gradient for the generic autograd path)
 __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -85,10 +86,13 @@ static int set_lds(KernelT kern, size_t lds) {
     return denet_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
 }
 
-// Launch geometry of upsample_loss_kernel, from the exact index rule (same float ops as the device).
+// Launch geometry of the loss kernels, from the exact index rule (same float ops as the device).
 struct LossGeom {
     int xsplit, rows_max, emax, xw_max, threads, ncmax, rsplit;
-    size_t lds;
+    size_t lds;          // upsample_loss_body<.,.,rsplit>
+    // chain path of the weighted CE (dev_wce_chain.hpp): em = 0 if the geometry is not covered
+    int em, kchunk;
+    size_t lds_chain;    // max(chain layout, exact body with one row group: the in-kernel fallback)
 };
 
 static int max_span(int in_size, int out_size) {      // widest set of dst indices sharing one upper tap
@@ -100,6 +104,15 @@ static int max_span(int in_size, int out_size) {      // widest set of dst indic
         prev = q;
     }
     return best;
+}
+
+// LDS bytes of upsample_loss_body
+static size_t exact_lds(int K, int ncmax, int rows_max, int emax, int xw_max, bool grad, int rsplit) {
+    size_t off = (size_t)(2 + 4 * (grad ? rsplit : 0)) * K * ncmax + K + 8 + xw_max;
+    off = (off + ncmax + 2 + 1) & ~(size_t)1;
+    off += grad ? (size_t)2 * rows_max * emax * ncmax : 0;
+    size_t lds = off * 4 + (size_t)rows_max * xw_max;
+    return (lds + 15) & ~(size_t)15;
 }
 
 static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g) {
@@ -125,14 +138,8 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         }
         // gradient pass items: (class, cell) x row groups.  Two row groups give K = 21 enough items for 256
         // threads; from ~500 (class, cell) pairs on, one group is enough and halves the accumulator arrays
-        // (K = 81: 62 -> 41 KB of LDS, three blocks per CU instead of two)
         const int rsplit = grad ? (K * (cwe + 1) >= 512 ? 1 : 2) : 0;
-        size_t off = (size_t)(2 + 4 * rsplit) * K * ncmax + K + 8 + xw_max;
-        off = (off + ncmax + 2 + 1) & ~(size_t)1;
-        off += grad ? (size_t)2 * rows_max * emax * ncmax : 0;
-        off += grad ? (size_t)2 * rows_max * ncmax + 2 : 0;   // per-(row, cell) shift pair + the fast-path flag
-        size_t lds = off * 4 + (size_t)rows_max * xw_max;
-        lds = (lds + 15) & ~(size_t)15;
+        const size_t lds = exact_lds(K, ncmax, rows_max, emax, xw_max, grad, rsplit);
         if (lds <= 64 * 1024 || (cw == 1 && lds <= 150 * 1024)) {
             g->xsplit = xsplit; g->rows_max = rows_max; g->emax = emax; g->xw_max = xw_max; g->threads = UL_T;
             g->ncmax = ncmax;
@@ -142,7 +149,39 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
             break;
         }
     }
-    return found;
+    if (!found) return false;
+    // chain path: cells of at most 16 label columns, the (row, cell) items of a block in one round of
+    // thread pairs, and a table chunk that keeps the block within ~40 KB of LDS (four blocks per CU) if
+    // it can, within 64 KB otherwise
+    g->em = 0;
+    g->kchunk = 0;
+    g->lds_chain = 0;
+    const int em = (emax == 8 || emax == 9) ? emax : 0;
+    if (em && 2 * rows_max * g->ncmax <= UL_T && rows_max * emax <= 500 /* 16-bit moment fields */) {
+        const size_t fb = exact_lds(K, g->ncmax, rows_max, emax, g->xw_max, grad, 1);
+        int best = 0;
+        for (int pass = 0; pass < 2 && !best; ++pass) {
+            const size_t cap = pass == 0 ? 40 * 1024 : 64 * 1024;
+            for (int kc = K; kc >= (K < 8 ? K : 8); --kc) {
+                if ((kc & 1) && kc != K) continue;          // class pairs must not straddle chunks
+                const size_t b = (size_t)wc_lds_floats(K, g->ncmax, rows_max, kc, em, grad) * 4;
+                if (b <= cap) { best = kc; break; }
+            }
+        }
+        if (best && best < K) {
+            // equal chunks of an even size (81 with room for 30 -> 3 chunks of 28, 28, 25)
+            const int nchunk = (K + best - 1) / best;
+            best = ((K + nchunk - 1) / nchunk + 1) & ~1;
+        }
+        if (best && fb <= 64 * 1024) {
+            size_t b = (size_t)wc_lds_floats(K, g->ncmax, rows_max, best, em, grad) * 4;
+            b = (b + 15) & ~(size_t)15;
+            g->em = em;
+            g->kchunk = best;
+            g->lds_chain = b > fb ? b : fb;
+        }
+    }
+    return true;
 }
 
 extern "C" int64_t denet_upsample_loss_parts(int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, int with_grad) {
@@ -152,61 +191,31 @@ extern "C" int64_t denet_upsample_loss_parts(int64_t K, int64_t h, int64_t w, in
     return (int64_t)h * g.xsplit;
 }
 
-// The uniform-step kernels (UNI) apply when the horizontal scale (w-1)/(W-1) is a power of two: then
-// scale * x is exact in fp32 for every label column x, so the lerp weights inside a cell are an exact
-// arithmetic progression with step `scale` (dev_upsample_loss.hpp).
-static float uniform_step(int w, int W) {
-    const float sx = bilinear_scale(w, W);
-    if (!(sx > 0.f) || sx >= 1.f) return 0.f;
-    int ex;
-    return frexpf(sx, &ex) == 0.5f ? sx : 0.f;
-}
-
 static int launch_loss(int mode, bool grad, const float* logits, const int64_t* Y, const float* wgt, int64_t N,
                        int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, float alpha, float gamma, float* part,
                        float* da, float* db, hipStream_t st) {
     LossGeom g;
     if (!loss_geom((int)K, (int)h, (int)w, (int)H, (int)W, grad, &g)) return DENET_E_UNSUPPORTED;
     dim3 grid((unsigned)(h * g.xsplit), (unsigned)N), block((unsigned)g.threads);
-    const float dw = uniform_step((int)w, (int)W);
     LossArgs a{logits, Y, wgt, (int)K, (int)h, (int)w, (int)H, (int)W, g.xsplit, g.rows_max, g.emax, g.xw_max,
-               alpha, gamma, part, da, db, dw};
-#define UL_GO(M, G)                                                                                          \
+               alpha, gamma, part, da, db, g.kchunk, bilinear_scale((int)h, (int)H), bilinear_scale((int)w, (int)W)};
+#define UL_GO(KERN, LDS)                                                                                     \
     {                                                                                                        \
-        int rc = set_lds(upsample_loss_kernel<M, G>, g.lds);                                                 \
+        int rc = set_lds(KERN, LDS);                                                                         \
         if (rc) return rc;                                                                                   \
-        hipLaunchKernelGGL((upsample_loss_kernel<M, G>), grid, block, g.lds, st, a);                         \
+        hipLaunchKernelGGL(KERN, grid, block, LDS, st, a);                                                   \
     }
-#define UL_GO3(M, G, NC)                                                                                     \
-    {                                                                                                        \
-        int rc = set_lds(upsample_loss_kernel<M, G, NC>, g.lds);                                             \
-        if (rc) return rc;                                                                                   \
-        hipLaunchKernelGGL((upsample_loss_kernel<M, G, NC>), grid, block, g.lds, st, a);                     \
+    if (mode == 1) {
+        hipLaunchKernelGGL(focal_kernel, grid, block, 0, st, a);
     }
-    if (mode == 0) {
-        if (grad) {
-            // instantiation: LDS stride constant (NCM 16 / run time), uniform-step arithmetic, row groups
-#define UL_GRAD(NC, U, RSV)                                                                                  \
-    {                                                                                                        \
-        int rc = set_lds(upsample_loss_kernel<0, true, NC, U, RSV>, g.lds);                                  \
-        if (rc) return rc;                                                                                   \
-        hipLaunchKernelGGL((upsample_loss_kernel<0, true, NC, U, RSV>), grid, block, g.lds, st, a);          \
-    }
-            const bool n16 = g.ncmax == 16, uni = dw > 0.f;
-            if (g.rsplit == 2) {
-                if (n16 && uni) UL_GRAD(16, true, 2) else if (uni) UL_GRAD(0, true, 2)
-                else if (n16) UL_GRAD(16, false, 2) else UL_GRAD(0, false, 2)
-            } else {
-                if (n16 && uni) UL_GRAD(16, true, 1) else if (uni) UL_GRAD(0, true, 1)
-                else if (n16) UL_GRAD(16, false, 1) else UL_GRAD(0, false, 1)
-            }
-#undef UL_GRAD
-        } else UL_GO(0, false)
-    } else {
-        UL_GO(1, false)
-    }
+    else if (g.em == 8 && grad) UL_GO((wce_chain_kernel<true, 8, 1>), g.lds_chain)
+    else if (g.em == 9 && grad) UL_GO((wce_chain_kernel<true, 9, 1>), g.lds_chain)
+    else if (g.em == 8) UL_GO((wce_chain_kernel<false, 8, 1>), g.lds_chain)
+    else if (g.em == 9) UL_GO((wce_chain_kernel<false, 9, 1>), g.lds_chain)
+    else if (!grad) UL_GO((upsample_loss_kernel<false, 2>), g.lds)
+    else if (g.rsplit == 2) UL_GO((upsample_loss_kernel<true, 2>), g.lds)
+    else UL_GO((upsample_loss_kernel<true, 1>), g.lds)
 #undef UL_GO
-#undef UL_GO3
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -218,33 +227,30 @@ int denet_loss_pair_fwd(const float* logits, const int64_t* Yq_full, const float
                         void* stream) {
     LossGeom g0, g1;
     const bool grad = da != nullptr;
-    const float dw = uniform_step((int)w, (int)W);
     if (!loss_geom((int)K, (int)h, (int)w, (int)H, (int)W, grad, &g0)) return DENET_E_UNSUPPORTED;
     if (!loss_geom(2, (int)h, (int)w, (int)H, (int)W, false, &g1)) return DENET_E_UNSUPPORTED;
     if (N + NB > 65535) return DENET_E_UNSUPPORTED;
     const int nb0 = (int)h * g0.xsplit, nb1 = (int)h * g1.xsplit;
-    const size_t lds = g0.lds > g1.lds ? g0.lds : g1.lds;
+    const size_t lds = g0.em ? g0.lds_chain : g0.lds;       // (the focal blocks use 8 floats of it)
     LossArgs a0{logits, Yq_full, wgt, (int)K, (int)h, (int)w, (int)H, (int)W, g0.xsplit, g0.rows_max, g0.emax,
-                g0.xw_max, 0.f, 0.f, part_k, da, db, dw};
+                g0.xw_max, 0.f, 0.f, part_k, da, db, g0.kchunk, bilinear_scale((int)h, (int)H), bilinear_scale((int)w, (int)W)};
     LossArgs a1{logits_binary, Yq, nullptr, 2, (int)h, (int)w, (int)H, (int)W, g1.xsplit, g1.rows_max, g1.emax,
-                g1.xw_max, alpha, gamma, part_p, nullptr, nullptr, 0.f};
+                g1.xw_max, alpha, gamma, part_p, nullptr, nullptr, 0, bilinear_scale((int)h, (int)H), bilinear_scale((int)w, (int)W)};
     dim3 grid((unsigned)(nb0 > nb1 ? nb0 : nb1), (unsigned)(N + NB)), block(UL_T);
     hipStream_t st = (hipStream_t)stream;
-#define UL_PAIR(...)                                                                                         \
+#define UL_PAIR(KERN)                                                                                        \
     {                                                                                                        \
-        int rc = set_lds(upsample_loss_pair_kernel<__VA_ARGS__>, lds);                                       \
+        int rc = set_lds(KERN, lds);                                                                         \
         if (rc) return rc;                                                                                   \
-        hipLaunchKernelGGL((upsample_loss_pair_kernel<__VA_ARGS__>), grid, block, lds, st, a0, a1, (int)N, nb0, nb1); \
+        hipLaunchKernelGGL(KERN, grid, block, lds, st, a0, a1, (int)N, nb0, nb1);                            \
     }
-    const bool n16 = g0.ncmax == 16, uni = dw > 0.f;
-    if (!grad) UL_PAIR(false)
-    else if (g0.rsplit == 2) {
-        if (n16 && uni) UL_PAIR(true, 16, true, 2) else if (uni) UL_PAIR(true, 0, true, 2)
-        else if (n16) UL_PAIR(true, 16, false, 2) else UL_PAIR(true, 0, false, 2)
-    } else {
-        if (n16 && uni) UL_PAIR(true, 16, true, 1) else if (uni) UL_PAIR(true, 0, true, 1)
-        else if (n16) UL_PAIR(true, 16, false, 1) else UL_PAIR(true, 0, false, 1)
-    }
+    if (g0.em == 8 && grad) UL_PAIR((wce_chain_pair_kernel<true, 8, 1>))
+    else if (g0.em == 9 && grad) UL_PAIR((wce_chain_pair_kernel<true, 9, 1>))
+    else if (g0.em == 8) UL_PAIR((wce_chain_pair_kernel<false, 8, 1>))
+    else if (g0.em == 9) UL_PAIR((wce_chain_pair_kernel<false, 9, 1>))
+    else if (!grad) UL_PAIR((upsample_loss_pair_kernel<false, 2>))
+    else if (g0.rsplit == 2) UL_PAIR((upsample_loss_pair_kernel<true, 2>))
+    else UL_PAIR((upsample_loss_pair_kernel<true, 1>))
 #undef UL_PAIR
     DENET_CHECK_LAUNCH();
     return DENET_OK;

@@ -38,9 +38,10 @@ def process_nway(Yq_pre: torch.Tensor, way: int):
     background, 2i+1 its foreground; the shared background is the max over the way backgrounds,
     and way i's binary pair is get_binary_logits([bg, fg_0..fg_{way-1}], label = i + 1).
 
-    Parity note: trainer/utils.py cannot be imported in the build container (it pulls in
-    torchvision through model.head), so this function is restated from the source text and checked
-    against a plain-PyTorch restatement of the same lines (tests/test_gpu_api.py): parity unpinned."""
+    Pinned by tests/golden/trainer_glue.npz: trainer/utils.py itself cannot be imported in the build
+    container (it pulls in torchvision through model.head), so oracle/gen_golden.py restates its
+    index_select / max / cat glue around the reference's own get_binary_logits; the result must be
+    bit-identical (tests/test_gpu_api.py)."""
     N = Yq_pre.shape[0]
     x = Yq_pre.detach().float()
     background = x[:, 0::2].max(dim=1, keepdim=True)[0]

@@ -9,17 +9,23 @@ re-weighting of the novel class (1-way only), only ``loss_k`` back-propagated,
 per-way BinaryIOU updates for way > 1, the checkpoint dictionary
 (trainer/trainers.py:174-183) and `fix_randomness` for testing.
 
-Changed on purpose: the logits are not up-sampled to label resolution before
-the loss and the metrics (the kernels do it on the fly), so `Yq_pre` /
-`Yq_full_pre` are returned at feature resolution unless
-`materialize_upsampled: true` is configured; tensorboard / matplotlib output,
-the PIL datasets and the ImageNet backbone are outside this path -- episodes
-come from `data.*_dataset: synthetic` and the backbone may be the stub
+`step()` returns `Yq_pre [N*way,2,H,W]` and `Yq_full_pre [N,K,H,W]` up-sampled to the label resolution,
+as the reference does (trainer/trainers.py:954-956,1003-1005); the loss itself never reads those
+tensors (the loss kernels up-sample on the fly from the low-res logits).  `materialize_upsampled: false`
+in the `train` / `test` section is the opt-out for loops that only feed the metrics: the outputs then stay
+at feature resolution and the metric kernels up-sample on the fly as well.
+
+Changed on purpose: tensorboard / matplotlib output, the PIL datasets and the ImageNet backbone are
+outside this path -- episodes come from `data.*_dataset: synthetic` and the backbone may be the stub
 `SyntheticBackbone` (`model.backbone: synthetic`).
 
-With WORLD_SIZE > 1 (torchrun) every rank owns a contiguous block of each
-episode batch; gradients are averaged with one flat all-reduce per step and the
-metric counts are summed once at the end (denet_amd/sharding.py).
+With WORLD_SIZE > 1 (torchrun) every rank owns a contiguous block of each episode batch (batch sizes
+must be multiples of the world size: `loss_k` is a mean over the local episodes, so only equal shards make
+the averaged gradient the gradient of the global batch); gradients are averaged with one flat all-reduce
+per step and the metric counts are summed once at the end (denet_amd/sharding.py).  The running B-IOU /
+F-IOU that train() prints every `log_steps` are rank 0's shard only (labelled so); train_val() / test()
+print all-reduced values.  BatchNorm statistics of the conv stack are per shard (no SyncBN): rank 0's
+running buffers are the ones a checkpoint keeps.
 """
 from __future__ import annotations
 
@@ -38,6 +44,7 @@ from . import ops, sharding
 from .head import DENet, freeze_weights, get_architecture, key2arch
 from .losses import get_loss, loss_denet_batch
 from .metrics import BinaryIOU as bIOU, FullIOU as fIOU
+from .schedulers import get_scheduler
 from .synthetic import EpisodeShape, make_episodes
 
 
@@ -164,6 +171,23 @@ def DENet_forward_wrapper(model, arch, *args, **kwargs):
     raise ValueError('Architecture {} not supported'.format(arch))
 
 
+def nway_fusion_update(b_iou, pre, Yq, cls_idx, way, order_base=None):
+    """The n-way test fusion of the class-agnostic trainers (PatternTrainer.test,
+    trainer/trainers.py:838-866): `pre` (N, 2*way, H, W) = the `way` per-way binary predictions
+    concatenated along the channels, fused by process_nway into (N, way, 2, H, W), then one
+    BinaryIOU.update per way with that way's query mask Yq[:, i] and class ids cls_idx[:, i].
+    order_base: global position of this batch's first (way 0) update in a sharded run (see
+    BinaryIOU.all_reduce); None in a single process."""
+    from .operations import process_nway
+    fused = process_nway(pre, way)
+    N = pre.shape[0]
+    for i in range(way):
+        keys = None if order_base is None else order_base + i * N + np.arange(N)
+        cls = torch.select(torch.as_tensor(cls_idx), 1, i)
+        b_iou.update(torch.select(Yq, 1, i), torch.select(fused, 1, i).contiguous(), cls.cpu().numpy(), order_keys=keys)
+    return fused
+
+
 def _make_optimizer(name, params, **cfg):
     table = {'sgd': torch.optim.SGD, 'adam': torch.optim.Adam, 'adamw': torch.optim.AdamW,
              'rmsprop': torch.optim.RMSprop, 'adagrad': torch.optim.Adagrad}
@@ -191,7 +215,7 @@ class DENetTrainer(object):
             model_kwargs['backbone'] = SyntheticBackbone()
         self.model = get_architecture(arch)(**model_kwargs).to(self.dev)
         self.shot = self.data_cfg['shot']
-        self.materialize = bool(cfg.get('train', cfg.get('test', {})).get('materialize_upsampled', False))
+        self.materialize = bool(cfg.get('train', cfg.get('test', {})).get('materialize_upsampled', True))
         self.logdir = None
         self.best_bIOU, self.best_step, self.start_epoch = 0, 1, 1
         seed = self.data_cfg.get('seed', 0)
@@ -204,6 +228,7 @@ class DENetTrainer(object):
             opt = deepcopy(self.train_cfg['optimizer'])
             self.optimizer = _make_optimizer(opt.pop('name'), [p for p in self.model.parameters() if p.requires_grad],
                                              **opt)
+            self.scheduler = get_scheduler(self.optimizer, scheduler_dict=self.train_cfg.get('scheduler', None))
             self.bucket = sharding.GradBucket(self.model.parameters())
             self.loss_func = DENet_loss_wrapper(get_loss(self.train_cfg['loss']), arch=arch)
             self.num_steps = self.train_cfg['num_steps']
@@ -211,6 +236,7 @@ class DENetTrainer(object):
             self.val_steps = self.train_cfg.get('val_steps', 0)
             self.lambda_ = self.train_cfg.get('lambda', 1.0)
             bs = self.data_cfg['batch_size']
+            self._check_shardable(bs, self.data_cfg.get('batch_size_val') or bs)
             self.train_loader = get_loader(self.data_cfg['train_dataset'])(
                 self.data_cfg.get('batches_per_epoch', self.num_steps), bs, 1, self.shot, self.max_num_classes, img,
                 seed=seed, split='train')
@@ -225,6 +251,7 @@ class DENetTrainer(object):
             self.test_cfg = test_config['test']
             self.testing = True
             self.way = self.data_cfg['way']
+            self._check_shardable(self.data_cfg['batch_size'])
             self.test_loader = get_loader(self.data_cfg['dataset'])(
                 self.data_cfg.get('num_batches', 50), self.data_cfg['batch_size'], self.way, self.shot,
                 self.max_num_classes, img, seed=seed, split='test')
@@ -232,18 +259,28 @@ class DENetTrainer(object):
             if ckpt:
                 self._load_checkpoints(ckpt, is_testing=True)
 
+    def _check_shardable(self, *batch_sizes):
+        """An empty or unequal shard would leave one rank out of a collective (a hang) or change the mean
+        the all-reduce forms: refuse it up front, on every rank alike."""
+        for bs in batch_sizes:
+            if bs % self.world:
+                raise ValueError('batch size %d is not a multiple of the world size %d' % (bs, self.world))
+
     # ---- checkpoints: the reference's dictionary (trainer/trainers.py:174-195) -------------
     def _save_checkpoints(self, iter_idx, path):
         if self.rank != 0:
             return
         torch.save({'best_step': self.best_step, 'epoch': iter_idx, 'best_bIOU': self.best_bIOU,
                     'model': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
-                    'scheduler': {}}, path)
+                    'scheduler': self.scheduler.state_dict()}, path)
 
     def _load_checkpoints(self, path, is_testing=False):
         d = torch.load(path, map_location=self.dev, weights_only=True)
         self.start_epoch, self.best_step, self.best_bIOU = d['epoch'], d['best_step'], d['best_bIOU']
         self.model.load_state_dict(d['model'])
+        if not is_testing and d.get('scheduler'):
+            # resume (trainer/trainers.py:192-194); LambdaLR keeps its factor functions out of the state
+            self.scheduler.load_state_dict(d['scheduler'])
 
     # ---- one step (trainer/trainers.py:936-1005) --------------------------------------------
     def step(self, data, train=True, **kwargs):
@@ -275,10 +312,15 @@ class DENetTrainer(object):
     # ---- loops ------------------------------------------------------------------------------
     def train(self):
         timer = Timer()
-        step_idx = 0
+        where = 'Train' if self.world == 1 else 'Train (rank-0 shard)'
         for epoch_idx in range(self.start_epoch, self.num_epoch + 1):
+            # per-epoch reset of the running metrics / meters and the scheduler tick (trainer/trainers.py:205-209)
+            self.b_iou, self.f_iou = bIOU(), fIOU(num_classes=self.max_num_classes)
+            for m in self.meters.values():
+                m.reset()
+            self.scheduler.step()
             for batch_idx, batch in enumerate(self.train_loader, 1):
-                step_idx += 1
+                step_idx = (epoch_idx - 1) * len(self.train_loader) + batch_idx
                 Yq_pre, Yq_full_pre, loss, loss_k, loss_p = self.step(batch, train=True)
                 local = sharding.shard_batch(tuple(batch), self.rank, self.world)
                 self.b_iou.update(local[3], Yq_pre, local[4].numpy())
@@ -286,9 +328,9 @@ class DENetTrainer(object):
                 for k, v in (('loss', loss), ('loss_k', loss_k), ('loss_p', loss_p)):
                     self.meters[k].update(v)
                 if self.rank == 0 and step_idx % self.log_steps == 0:
-                    print('Epoch %d (%2d/%2d), Step %d, Train, Loss %.4f, B-IOU %.4f, F-IOU %.4f, %s' % (
-                        epoch_idx, batch_idx, len(self.train_loader), step_idx, loss, self.b_iou.mean_iou(),
-                        self.f_iou.mean_iou(), timer.measure()))
+                    print('Epoch %d (%2d/%2d), Step %d, %s, Loss %.4f, B-IOU %.4f, F-IOU %.4f, lr %.2e, %s' % (
+                        epoch_idx, batch_idx, len(self.train_loader), step_idx, where, loss, self.b_iou.mean_iou(),
+                        self.f_iou.mean_iou(), self.scheduler.get_last_lr()[0], timer.measure()))
                 if self.val_steps and step_idx % self.val_steps == 0:
                     self.train_val(epoch_idx, step_idx)
                 if step_idx == self.num_steps:

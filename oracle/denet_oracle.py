@@ -141,6 +141,15 @@ def binary_logits(logits_full, label, base=True):
     return torch.stack([bg, fg], dim=1)
 
 
+def process_nway(Yq_pre, way):
+    """(N, 2*way, h, w) -> (N, way, 2, h, w): shared background = max over the way backgrounds (even
+    channels), then binary_logits([bg, fg_0..], label = i + 1) per way  (trainer/utils.py:128-154)."""
+    N = Yq_pre.shape[0]
+    bg = Yq_pre[:, 0::2].max(dim=1, keepdim=True)[0]
+    scores = torch.cat([bg, Yq_pre[:, 1::2]], dim=1)
+    return torch.stack([binary_logits(scores, torch.full([N], i + 1, dtype=torch.int64)) for i in range(way)], dim=1)
+
+
 def head_forward(Fq, Fs, Ys, label, p, gate_mask=None, weight_mask=None):
     """DENet.forward after the feature producer (model/head/denet.py:57-93).
     label is [N] (way==1) or [N,way]. Returns (logits_full, logits_binary, Wn)."""

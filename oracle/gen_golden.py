@@ -311,8 +311,66 @@ def capture_api_cases():
     print("api_cases.npz", len(keys), "state_dict entries")
 
 
+def ref_process_nway(Yq_pre, way):
+    """trainer/utils.py:128-154 (the module cannot be imported: it pulls in torchvision through model.head):
+    the index_select / max / cat glue restated around the REFERENCE's own get_binary_logits."""
+    N = Yq_pre.shape[0]
+    background = Yq_pre.index_select(1, torch.tensor([2 * i for i in range(way)])).max(dim=1, keepdim=True)[0]
+    foreground = Yq_pre.index_select(1, torch.tensor([2 * i + 1 for i in range(way)]))
+    scores = torch.cat([background, foreground], dim=1)
+    outs = [ref_ops.get_binary_logits(scores, torch.full([N], i + 1, dtype=torch.int64)) for i in range(way)]
+    return torch.stack(outs, dim=1)
+
+
+def capture_trainer_glue():
+    """T1 / N4: what DENetTrainer.step returns (the two logit tensors up-sampled by ATen,
+    trainer/trainers.py:954-956) and the n-way fusion of PatternTrainer.test (trainer/trainers.py:831-873:
+    per-way class-agnostic predictions -> cat -> process_nway -> per-way BinaryIOU with the reference's
+    own metric class)."""
+    s = EpisodeShape("glue", N=2, way=2, shot=3, K=9, c=64, h=7, w=9, H=50, W=70, config_index=105)
+    ep = make_episodes(s, ignore_rows=3)
+    state = make_estimator_state(s.K, s.c)
+    d = {("in:" + k): v.float().numpy() if v.is_floating_point() else v.numpy() for k, v in ep.items()}
+    d.update({("param:" + k): v.numpy() for k, v in state.items()})
+    d["shape"] = np.array([s.N, s.way, s.shot, s.K, s.c, s.h, s.w, s.H, s.W], dtype=np.int64)
+    with torch.no_grad():
+        we = build_estimator(s.K, s.c, state).eval()
+        full, binl = ref_denet_tail(we, ep["Fq"].float(), ep["Fs"].float(), ep["Ys"], ep["label"])
+        size = ep["Yq_full"].shape[-2:]
+        d["out:full_up"] = F.interpolate(full, size=size, mode="bilinear", align_corners=True).numpy()
+        d["out:bin_up"] = F.interpolate(binl.float(), size=size, mode="bilinear", align_corners=True).numpy()
+    # n-way fusion: `way` class-agnostic predictions per episode (what PatternTrainer.step returns per way)
+    g = torch.Generator().manual_seed(606)
+    way, N, H, W = 3, 4, 33, 41
+    bi = ref_metrics.BinaryIOU()
+    for u in range(2):
+        pre = torch.randn(N, 2 * way, H, W, generator=g)
+        pre[:, 2, :4] = pre[:, 0, :4]                     # ties between way backgrounds
+        Yq = torch.randint(0, 2, (N, way, H, W), generator=g)
+        if u == 0:
+            Yq[1, 2] = 0                                  # skipped (sample, way)
+        cls = torch.tensor([[3, 7, 1], [7, 2, 3], [5, 5, 1], [2, 8, 4]]) if u == 0 else \
+            torch.tensor([[9, 1, 2], [3, 3, 3], [6, 2, 7], [1, 4, 8]])
+        fused = ref_process_nway(pre, way)
+        for i in range(way):
+            bi.update(torch.select(Yq, 1, i), torch.select(fused, 1, i), torch.select(cls, 1, i).numpy())
+        d[f"in:nway_pre{u}"], d[f"in:nway_Yq{u}"], d[f"in:nway_cls{u}"] = pre.numpy(), Yq.numpy(), cls.numpy()
+        d[f"out:nway_fused{u}"] = fused.numpy()
+    keys = list(bi.inter.keys())
+    d["out:nway_keys"] = np.array(keys, dtype=np.int64)
+    d["out:nway_inter"] = np.array([bi.inter[k] for k in keys])
+    d["out:nway_union"] = np.array([bi.union[k] for k in keys])
+    d["out:nway_mean"] = np.float64(bi.mean_iou())
+    d["out:nway_bf"] = np.float64(bi.mean_bf_iou())
+    np.savez_compressed(os.path.join(OUT, "trainer_glue.npz"), **d)
+    print("trainer_glue.npz", d["out:nway_mean"], d["out:nway_bf"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "glue":     # only the fixture added in round 2
+        capture_trainer_glue()
+        sys.exit(0)
     torch.set_num_threads(8)
     s1 = EpisodeShape("g1", N=2, way=1, shot=5, K=21, c=64, h=9, w=9, H=65, W=65, config_index=101, lam=2.5)
     s2 = EpisodeShape("g2", N=2, way=2, shot=3, K=9, c=64, h=7, w=9, H=50, W=70, config_index=102)
@@ -326,3 +384,4 @@ if __name__ == "__main__":
     capture_index_tables()
     capture_fullsize_checksums()
     capture_api_cases()
+    capture_trainer_glue()

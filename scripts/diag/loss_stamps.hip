@@ -33,9 +33,9 @@ int main(int argc, char** argv) {
     const size_t nblk = (size_t)parts_k * 2 * N;
     unsigned long long* d_bs; CK(hipMalloc(&d_bs, nblk * 24)); CK(hipMemset(d_bs, 0, nblk * 24));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &d_bs, sizeof(d_bs)));
-    for (size_t l : {(size_t)0, (size_t)8192, (size_t)16384, (size_t)20000, (size_t)23400, (size_t)30000, (size_t)40000}) {
+    for (size_t l : {(size_t)0, (size_t)8192, (size_t)16384, (size_t)20000, (size_t)23400, (size_t)30000, (size_t)33000, (size_t)40000}) {
         int nb = -1;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, upsample_loss_pair_kernel<true>, 256, l));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wce_chain_pair_kernel<true, 8, 1>, 256, l));
         printf("occupancy(pair<true>, lds=%zu) = %d blocks/CU\n", l, nb);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -27,3 +27,19 @@ def rel_err(a, b):
     a = torch.as_tensor(a).detach().double()
     b = torch.as_tensor(b).detach().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elem_err(a, b, rtol=1e-3, afloor=1e-6):
+    """Element-wise bound: the worst |a-b| / (rtol*|b| + afloor*max|b|).  <= 1 means every entry is within
+    `rtol` RELATIVE to itself, with an absolute floor for entries that are tiny next to the tensor's
+    largest (north_star: "within 1e-3 relative"; rel_err above only bounds the error by the largest entry)."""
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
+    bound = rtol * b.abs() + afloor * b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs() / bound).max())
+
+
+def assert_close(a, b, tol, name="", rtol=1e-3, afloor=1e-6):
+    """max-normalised error below `tol` AND every entry within rtol of itself (+ floor)."""
+    r, e = rel_err(a, b), elem_err(a, b, rtol, afloor)
+    assert r < tol and e <= 1.0, f"{name}: max-normalised error {r:.3e} (bar {tol:.1e}), element-wise {e:.3f} of its bound"

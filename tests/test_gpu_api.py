@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, GOLDEN, load_case, rel_err
+from helpers import CASES, GOLDEN, assert_close, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 TIGHT = 2e-5
@@ -183,7 +183,8 @@ def test_trainer_train_val_test_roundtrip(dev, tmp_path):
     batch = tr.train_loader.batch(0)
     with torch.no_grad():
         first = tr.step(batch, train=False)                # eval mode: deterministic loss
-    assert len(first) == 5 and first[0].shape == (4, 2, 9, 9) and first[1].shape == (4, 21, 9, 9)
+    # reference-shaped outputs by default: up-sampled to the label size (trainer/trainers.py:954-956,1003-1005)
+    assert len(first) == 5 and first[0].shape == (4, 2, 65, 65) and first[1].shape == (4, 21, 65, 65)
     assert abs(first[2] - (first[3] + first[4])) < 1e-5
     before = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
     out = tr.step(batch, train=True)
@@ -212,23 +213,54 @@ def test_trainer_train_val_test_roundtrip(dev, tmp_path):
     }
     te = DENetTrainer(train_config=None, test_config=tcfg)
     out = te.step(te.test_loader.batch(0), train=False)
-    assert len(out) == 2 and out[0].shape == (8, 2, 9, 9)
+    assert len(out) == 2 and out[0].shape == (8, 2, 65, 65) and out[1].shape == (4, 21, 65, 65)
     mb, mf = te.test()
     assert 0.0 <= mb <= 1.0 and 0.0 <= mf <= 1.0
+    # opt-out: outputs stay at feature resolution, the metric kernels up-sample on the fly -> same counts
+    tcfg["test"]["materialize_upsampled"] = False
+    tl = DENetTrainer(train_config=None, test_config=tcfg)
+    out = tl.step(tl.test_loader.batch(0), train=False)
+    assert out[0].shape == (8, 2, 9, 9) and out[1].shape == (4, 21, 9, 9)
+    mb2, mf2 = tl.test()
+    assert abs(mb2 - mb) < 5e-3 and abs(mf2 - mf) < 5e-3      # a few sub-margin arg-max flips at most
     with pytest.raises(ValueError):
         DENetTrainer(cfg, tcfg)
 
 
-def test_process_nway_matches_restatement(dev):
-    """trainer/utils.py:128-154 (parity unpinned: the reference module cannot be imported here)."""
+def test_step_outputs_match_reference_upsampling(dev, golden_dir):
+    """T1: the tensors DENetTrainer.step returns are the reference's F.interpolate(bilinear,
+    align_corners=True) of both logit tensors (trainer/trainers.py:954-956), captured from ATen."""
+    from denet_amd import ops
+    from denet_amd.head import WeightEstimator
+    z = np.load(golden_dir + "/trainer_glue.npz")
+    N, way, shot, K, c, h, w, H, W = [int(v) for v in z["shape"]]
+    we = WeightEstimator(K, c).to(dev).eval()
+    we.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")})
+    with torch.no_grad():
+        full, binl = we.forward_with_binary(torch.from_numpy(z["in:Fq"]).to(dev), torch.from_numpy(z["in:Fs"]).to(dev),
+                                            torch.from_numpy(z["in:Ys"]).to(dev), torch.from_numpy(z["in:label"]).to(dev))
+        full_up = ops.upsample_bilinear(full, (H, W)).cpu()
+        bin_up = ops.upsample_bilinear(binl, (H, W)).cpu()
+    assert full_up.shape == (N, K, H, W) and bin_up.shape == (N * way, 2, H, W)
+    assert_close(full_up, z["out:full_up"], 2e-5, "full_up")
+    assert_close(bin_up, z["out:bin_up"], 2e-5, "bin_up")
+
+
+def test_process_nway_and_nway_fusion_match_reference(dev, golden_dir):
+    """N4: process_nway (trainer/utils.py:128-154) bit for bit against the fixture built around the
+    reference's own get_binary_logits, and the n-way test fusion of PatternTrainer.test
+    (trainer/trainers.py:831-873) with per-way BinaryIOU against the reference's metric class."""
+    from denet_amd.metrics import BinaryIOU
     from denet_amd.operations import process_nway
-    g = torch.Generator().manual_seed(5)
-    way, N = 3, 4
-    x = torch.randn(N, 2 * way, 7, 9, generator=g)
-    got = process_nway(x.to(dev), way).cpu()
-    bg = x[:, 0::2].max(1, keepdim=True)[0]
-    scores = torch.cat([bg, x[:, 1::2]], 1)
-    for i in range(way):
-        keep = [k for k in range(way + 1) if k != i + 1]
-        ref = torch.stack([scores[:, keep].max(1)[0], scores[:, i + 1]], 1)
-        assert torch.equal(got[:, i], ref)
+    from denet_amd.trainer import nway_fusion_update
+    z = np.load(golden_dir + "/trainer_glue.npz")
+    bi = BinaryIOU()
+    for u in range(2):
+        pre = torch.from_numpy(z[f"in:nway_pre{u}"]).to(dev)
+        way = pre.shape[1] // 2
+        assert torch.equal(process_nway(pre, way).cpu(), torch.from_numpy(z[f"out:nway_fused{u}"]))
+        nway_fusion_update(bi, pre, torch.from_numpy(z[f"in:nway_Yq{u}"]), torch.from_numpy(z[f"in:nway_cls{u}"]), way)
+    assert list(bi.inter.keys()) == z["out:nway_keys"].tolist()                  # dict insertion order
+    assert [bi.inter[k] for k in bi.inter] == z["out:nway_inter"].tolist()
+    assert [bi.union[k] for k in bi.union] == z["out:nway_union"].tolist()
+    assert bi.mean_iou() == float(z["out:nway_mean"]) and bi.mean_bf_iou() == float(z["out:nway_bf"])

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, rel_err
+from helpers import GOLDEN, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 ORDER = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
@@ -55,7 +55,8 @@ def test_c2_fullsize_against_reference_checksums(dev):
     for name, t in got.items():
         flat = t.detach().reshape(-1).cpu()
         ref = torch.from_numpy(z["val:" + name])
-        assert rel_err(flat[torch.from_numpy(z["idx:" + name])], ref) < 1e-3, name
+        # sampled entries: max-normalised and element-wise (the floor is relative to the sample's largest entry)
+        assert_close(flat[torch.from_numpy(z["idx:" + name])], ref, 1e-3, name)
         scale = float(z["abs:" + name])
         assert abs(float(flat.double().sum()) - float(z["sum:" + name])) < 1e-4 * scale + 1e-12, name
         assert abs(float(flat.double().abs().sum()) - scale) < 1e-4 * scale + 1e-12, name

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, load_case, rel_err
+from helpers import CASES, assert_close, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -98,7 +98,7 @@ def test_backward_chain(name, dev):
     assert rel_err(Fq.grad.cpu(), z["out:dFq"]) < TOL
     assert rel_err(Fs.grad.cpu(), z["out:dFs"]) < TOL
     for k in order:
-        assert rel_err(P_[k].grad.cpu(), z["grad:" + k]) < TOL, k
+        assert_close(P_[k].grad.cpu(), z["grad:" + k], TOL, k)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -122,10 +122,11 @@ def test_fused_head_step(name, dev):
     assert rel_err(binl.cpu(), z["out:logits_binary"]) < TIGHT
     assert rel_err(lk.detach().cpu(), z["out:loss_k"]) < 1e-4
     assert rel_err(lp.cpu(), z["out:loss_p"]) < 1e-4
-    assert rel_err(Fq.grad.cpu(), z["out:dFq"]) < TOL
-    assert rel_err(Fs.grad.cpu(), z["out:dFs"]) < TOL
+    assert_close(logits.cpu(), z["out:logits_full"], TIGHT, "logits_full")
+    assert_close(Fq.grad.cpu(), z["out:dFq"], TOL, "dFq")
+    assert_close(Fs.grad.cpu(), z["out:dFs"], TOL, "dFs")
     for k, t in zip(order, P_):
-        assert rel_err(t.grad.cpu(), z["grad:" + k]) < TOL, k
+        assert_close(t.grad.cpu(), z["grad:" + k], TOL, k)
 
 
 def test_metrics_boundary_bit_exact(dev, golden_dir):

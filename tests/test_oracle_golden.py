@@ -88,3 +88,25 @@ def test_index_rules(golden_dir):
 def test_planted_margin_is_wide(golden_dir):
     z = np.load(golden_dir + "/planted_1way_1shot.npz")
     assert float(z["out:min_margin"]) > 1e-4
+
+
+def test_trainer_glue_fixture(golden_dir):
+    """T1 / N4 rows: up-sampled step outputs and the n-way fusion, oracle vs the reference capture."""
+    z = np.load(golden_dir + "/trainer_glue.npz")
+    N, way, shot, K, c, h, w, H, W = [int(v) for v in z["shape"]]
+    params = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
+    full, binl, _ = O.head_forward(torch.from_numpy(z["in:Fq"]), torch.from_numpy(z["in:Fs"]), torch.from_numpy(z["in:Ys"]),
+                                torch.from_numpy(z["in:label"]), params)
+    assert rel_err(O.upsample(full, (H, W)), z["out:full_up"]) < TOL
+    assert rel_err(O.upsample(binl, (H, W)), z["out:bin_up"]) < TOL
+    bi = O.BinaryIOUOracle()
+    for u in range(2):
+        pre = torch.from_numpy(z[f"in:nway_pre{u}"])
+        nway = pre.shape[1] // 2
+        fused = O.process_nway(pre, nway)
+        assert torch.equal(fused, torch.from_numpy(z[f"out:nway_fused{u}"]))
+        Yq, cls = z[f"in:nway_Yq{u}"], z[f"in:nway_cls{u}"]
+        for i in range(nway):
+            bi.update(Yq[:, i], fused[:, i].max(1)[1].numpy(), cls[:, i])
+    assert list(bi.inter.keys()) == z["out:nway_keys"].tolist()
+    assert bi.mean_iou() == float(z["out:nway_mean"]) and bi.mean_bf_iou() == float(z["out:nway_bf"])
