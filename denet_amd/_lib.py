@@ -29,6 +29,7 @@ _SIGS = {
     "denet_masked_pool_fwd": "piL" "llllll" "FFF",
     "denet_proto_extend_fwd": "FFFFFFFFF" "L" "FF" "llllll" "FFFFF",
     "denet_proto_extend_bwd": "Fl" "FFFFF" "FFF" "LFF" "llllll" "FFFFFFFF" "pl",
+    "denet_proto_extend_bwd_static": "Fl" "FFFFF" "FFF" "LFF" "llllll" "FFFFFFFF",
     "denet_classify_fwd": "piFL" "lllll" "i" "FF",
     "denet_classify_shared_fwd": "piF" "llll" "F",
     "denet_classify_bwd": "piF" "FFFF" "llll" "pF",
@@ -51,6 +52,7 @@ _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
     "denet_strerror": (ctypes.c_char_p, "i"),
     "denet_proto_extend_bwd_workspace": (ctypes.c_int64, "lllll"),
+    "denet_proto_extend_bwd_static_limit": (ctypes.c_int64, ""),
     "denet_classify_bwd_parts": (ctypes.c_int64, "l"),
     "denet_head_step_workspace": (ctypes.c_int64, "lllllllll"),
     "denet_upsample_loss_parts": (ctypes.c_int64, "llllli"),

@@ -25,6 +25,9 @@ extern "C" const char* denet_strerror(int code) {
         case DENET_E_UNSUPPORTED: return "shape or dtype outside what the kernels support";
         case DENET_E_LAUNCH: return "kernel launch failed";
         case DENET_E_WORKSPACE: return "workspace too small";
+        case DENET_E_STATIC_LIMIT:
+            return "problem needs more scratch than the static buffer of the no-allocation entry point holds "
+                   "(denet_proto_extend_bwd_static_limit); use the workspace variant";
         default: return "unknown error";
     }
 }

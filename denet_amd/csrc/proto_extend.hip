@@ -15,6 +15,7 @@
 // split over 512/C thread groups; loads are coalesced across columns.
 #include "denet_common.hpp"
 #include "dev_proto_extend.hpp"
+#include <mutex>
 
 #define PE_THREADS 512
 
@@ -299,6 +300,56 @@ extern "C" int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part, con
         return rc;
     return denet_pe_bwd_params(u1, u2, u3, S, hidden, pool, dWn_part, 1, labels, weight_mask, N, way, shot, K, C, P,
                                dW1, db1, dW2, db2, dWl, dbl, dweight, stream);
+}
+
+// ---------------------------------------------------------------------------
+// The same backward for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): the scratch that denet_proto_extend_bwd takes as `ws` lives in a file-scope device array.
+// The array's NAME is only a host-side stand-in: its device address is looked up once per device with
+// hipGetSymbolAddress and that pointer -- never the name -- is what the kernels receive.
+// ---------------------------------------------------------------------------
+#define PE_STATIC_SCRATCH_BYTES (1 << 20)
+static __device__ __align__(256) float scratch[PE_STATIC_SCRATCH_BYTES / 4];
+
+#define PE_MAX_DEVICES 64
+static float* g_scratch_ptr[PE_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// device address of `scratch` on the CURRENT device (each GPU holds its own copy at its own address)
+static int pe_static_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PE_MAX_DEVICES) return DENET_E_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return DENET_E_LAUNCH;
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return DENET_OK;
+}
+
+extern "C" int64_t denet_proto_extend_bwd_static_limit(void) { return PE_STATIC_SCRATCH_BYTES; }
+
+extern "C" int denet_proto_extend_bwd_static(const float* dWn_part, int64_t n_part, const float* S, const float* cnt,
+                                             const float* hidden, const float* gate, const float* pool,
+                                             const float* W1, const float* W2, const float* Wl,
+                                             const int64_t* labels, const float* gate_mask,
+                                             const float* weight_mask, int64_t N, int64_t way, int64_t shot,
+                                             int64_t K, int64_t C, int64_t P, float* dW1, float* db1, float* dW2,
+                                             float* db2, float* dWl, float* dbl, float* dweight, float* coef,
+                                             void* stream) {
+    const int64_t need = denet_proto_extend_bwd_workspace(N, way, shot, K, C);
+    if (need < 0) return (int)need;
+    if (need > PE_STATIC_SCRATCH_BYTES) return DENET_E_STATIC_LIMIT;
+    float* ptr = nullptr;
+    const int rc = pe_static_scratch(&ptr);
+    if (rc) return rc;
+    // every intermediate in the scratch (u1, u2, u3, the tile-reduced dWn) is fully written by the kernels
+    // before it is read, so nothing of the previous call's contents has to be cleared
+    return denet_proto_extend_bwd(dWn_part, n_part, S, cnt, hidden, gate, pool, W1, W2, Wl, labels, gate_mask,
+                                  weight_mask, N, way, shot, K, C, P, dW1, db1, dW2, db2, dWl, dbl, dweight, coef,
+                                  ptr, PE_STATIC_SCRATCH_BYTES, stream);
 }
 
 // dWn[n] = sum over position tiles of the slabs K3b wrote, as a tensor (the gradient of

@@ -35,6 +35,7 @@ extern "C" {
 #define DENET_E_UNSUPPORTED -2  /* shape outside what the kernels were built for    */
 #define DENET_E_LAUNCH     -3   /* hipLaunchKernel reported an error                */
 #define DENET_E_WORKSPACE  -4   /* workspace too small                              */
+#define DENET_E_STATIC_LIMIT -5 /* beyond the static scratch of a no-allocation entry point */
 
 #define DENET_F32  0
 #define DENET_BF16 1
@@ -104,6 +105,25 @@ int denet_proto_extend_bwd(const float* dWn_part, int64_t n_part,
                            float* dW1, float* db1, float* dW2, float* db2, float* dWl, float* dbl,
                            float* dweight /*[K,C]*/, float* coef /*[B,C]*/,
                            void* ws, int64_t ws_bytes, void* stream);
+
+/* The same backward with NO workspace argument and no allocation of any kind (no hipMalloc / hipFree, no
+ * allocating library routine, no torch): the scratch lives in a static device array of
+ * denet_proto_extend_bwd_static_limit() bytes (1 MiB; every GPU the library runs on holds it until the process
+ * ends), so problems with denet_proto_extend_bwd_workspace(...) above that limit return DENET_E_STATIC_LIMIT.
+ * No counterpart in the reference: it exists for callers that cannot allocate -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  Same arguments, outputs and arithmetic as
+ * denet_proto_extend_bwd (it shares its kernels).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams or threads) race; serialise them.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress), so make one call outside any stream capture first. */
+int64_t denet_proto_extend_bwd_static_limit(void);
+int denet_proto_extend_bwd_static(const float* dWn_part, int64_t n_part,
+                                  const float* S, const float* cnt,
+                                  const float* hidden, const float* gate, const float* pool,
+                                  const float* W1, const float* W2, const float* Wl,
+                                  const int64_t* labels, const float* gate_mask, const float* weight_mask,
+                                  int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t P,
+                                  float* dW1, float* db1, float* dW2, float* db2, float* dWl, float* dbl,
+                                  float* dweight /*[K,C]*/, float* coef /*[B,C]*/, void* stream);
 
 /* ---- K3: per-pixel classifier (MFMA) + binary-logit extraction ----------
  * Replaces WeightEstimator.infer, training branch (model/common.py:390-394):
