@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU-baseline sample (seconds)")
     ap.add_argument("--breakdown", type=int, default=1, help="also report every kernel's duration (untimed pass)")
+    ap.add_argument("--collective", action="store_true",
+                    help="with one rank: still create the RCCL group and run the step's gradient all-reduce "
+                         "(exercises the N > 1 code path on a one-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,9 +120,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("DENET_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -128,8 +134,10 @@ def main():
     # gloo (dry runs only) has no AVG: it sums, which is the same exchange
     reduce_op = None if dist is None else (dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
 
-    # dry runs over gloo reduce through host memory (gloo's device-tensor path was seen to hang with two
-    # ranks on one GPU); RCCL reduces the device bucket in place
+    # Dry runs over gloo (two ranks sharing one GPU) reduce through host memory: gloo's DEVICE-tensor
+    # all-reduce hangs intermittently in that configuration with stock torch kernels as the only producers
+    # (scripts/diag_gloo_shared_gpu.py, mode `torch`: both ranks parked in all_reduce after 20-40 calls), so the
+    # round-1 hang was not the step's stream ordering.  RCCL (one rank per GPU) reduces the device bucket in place.
     host_reduce = dist is not None and dist.get_backend() != "nccl"
 
     shape = CONFIGS[args.config]
@@ -154,7 +162,7 @@ def main():
         st = torch.cuda.current_stream().cuda_stream if args.graph else stream     # capture runs on a side stream
         eng.run_forward(st)
         eng.run_backward(0, st)
-        if world > 1:
+        if dist is not None:
             # ONE all-reduce of the flat parameter-gradient bucket, enqueued behind the backward.
             # Measured on a one-rank RCCL group (scripts/diag_enqueue.py): splitting the last launch
             # (DENET_BWD_NO_DFS / ONLY_DFS) to overlap the all-reduce with the dFs stream costs 7 us for
@@ -218,7 +226,8 @@ def main():
     # ---- timed region ----
     pairs = {}
     if probe and graph is None:
-        every = max(1, args.probe_every)
+        # at least 8 samples whatever --steps is (the driver runs 20 steps)
+        every = max(1, min(args.probe_every, args.steps // 8))
         pairs = {i: (Event(), Event()) for i in range(0, args.steps, every)}
     if dist is not None:
         dist.barrier()
@@ -290,7 +299,7 @@ def main():
         del a, b
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.collective:
         from oracle import denet_oracle as O            # checker only: CPU baseline leg
         nthreads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
         torch.set_num_threads(nthreads)
@@ -326,14 +335,9 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
-        # Every collective of the run is behind us (the MAX of the elapsed times was the last one).
-        # Leave without tearing the process group down: on dry runs of this path (gloo, two ranks on
-        # one GPU) destroy_process_group, and a final barrier, were seen to hang after the result
-        # line had been printed; there is nothing left to clean up.
         sys.stdout.flush()
-        sys.stderr.flush()
-        time.sleep(0.5)          # let slower ranks drain their side of the last collective first
-        os._exit(0)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
