@@ -52,6 +52,31 @@ __device__ __forceinline__ void load2<unsigned short, false>(const unsigned shor
     b = pa + 1 < P ? bf16_to_f32(y) : 0.f;
 }
 
+// Branch-free form for every tile, partial ones included: ONE 8-byte (4-byte for bf16) load at a clamped
+// position (raw2_load), the pair shifted / zeroed by selects at the consumer (raw2_get).  (A `fast ? wide :
+// narrow` branch around the loads of a software-pipelined loop makes the compiler drain vmcnt(0) at the join:
+// the prefetch then runs serially.)
+template <typename T> struct Raw2;
+template <> struct Raw2<float> { typedef f32x2_u type; };
+template <> struct Raw2<unsigned short> { typedef unsigned type; };
+__device__ __forceinline__ f32x2_u raw2_load(const float* row, int pc) { return *reinterpret_cast<const f32x2_u*>(row + pc); }
+__device__ __forceinline__ unsigned raw2_load(const unsigned short* row, int pc) {
+    const u16x2_u v = *reinterpret_cast<const u16x2_u*>(row + pc);
+    return (unsigned)v[0] | ((unsigned)v[1] << 16);
+}
+// sh = pa - pc: 0 = both positions valid, 1 = the second loaded element is position pa (the last position of an
+// odd P), >= 2 = the lane's columns lie past P.  Output columns depend on their own B column only and columns
+// past P are never stored, so only the shifted case needs a select.
+__device__ __forceinline__ void raw2_get(const f32x2_u v, int sh, float& a, float& b) {
+    a = sh == 1 ? v[1] : v[0];
+    b = v[1];
+}
+__device__ __forceinline__ void raw2_get(const unsigned v, int sh, float& a, float& b) {
+    const float v0 = __uint_as_float(v << 16), v1 = __uint_as_float(v & 0xffff0000u);
+    a = sh == 1 ? v1 : v0;
+    b = v1;
+}
+
 // BUILD (fused step, sliced chain): Wn[n] does not exist yet.  The block assembles it in LDS while it
 // stages the tile -- base rows = weight * weight_mask[n] (dropout, model/common.py:326), the rows the
 // episode's ways overwrite = bl + sum of the projection's split-K partials (model/common.py:327-334,
@@ -61,46 +86,17 @@ struct WnBuild {
     float* Wn_out /*[N][K][C]*/;
 };
 
-// NW waves per block split the channels: NLD = C / (2 NW) k-steps per wave.
-template <typename T, int RT, int NLD, bool BUILD, int NW>
-__global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
-                                                          int64_t wn_stride, const int64_t* __restrict__ labels,
-                                                          int way, int K, int C, int P, int base,
-                                                          float* __restrict__ logits, float* __restrict__ bin,
-                                                          WnBuild wb) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int n = blockIdx.y, p0 = blockIdx.x * CL_TP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
+// Stage Wn[n] -> LDS [K][C+1] (16-byte loads, all of a thread's loads issued before the first store); BUILD:
+// assemble it on the way (see WnBuild).  NT threads, NSL = C / 16, SU = 16-byte loads per thread and pass.
+template <bool BUILD, int NT, int NSL, int SU>
+__device__ __forceinline__ void stage_wn(float* sm, const float* __restrict__ Wn, int64_t wn_stride,
+                                         const int64_t* __restrict__ labels, int way, int K, int C, int n,
+                                         const WnBuild& wb) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x;
     const int ldw = C + 1;
-
-    constexpr int NT = 64 * NW;
-    const int cper = C / NW;                       // channels per wave
-    const int cbeg = wave * cper;
-    const int pa = p0 + 2 * j;
-    const bool fast = (p0 + CL_TP <= P);           // block-uniform: only the last tile of an episode is partial
-    const T* fq = Fq + (int64_t)n * C * P;
-    // The streamed operand first: up to 64 channels (32 k-steps, 16 KB per wave) of Fq go in flight
-    // before anything else, so the Wn staging below hides under their latency.
-    STAMP(0);
-    constexpr int chunk = 2 * NLD;                 // channels per pass of this wave (== cper: C is 64 or 256)
-    float b0[NLD], b1[NLD];
-#ifdef DENET_DIAG_NO_FQ
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) { b0[u] = (float)u; b1[u] = 1.f; }
-#else
-    if (fast) {
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) load2<T, true>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
-    } else {
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) load2<T, false>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
-    }
-#endif
-
     // the rows this episode's ways overwrite: thread group jw = tid / 64 sums the partials of way jw
     // (16-byte column pieces, all loads in flight together, fixed order)
-    constexpr int NSL = NLD * NW / 8;              // C / 16
     f32x4 pv = {0.f, 0.f, 0.f, 0.f};
     int prow = -1;
     if constexpr (BUILD) {
@@ -127,7 +123,6 @@ __global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restri
         const int64_t* lab = labels + (int64_t)n * way;
         const int nv = (K * C) >> 2;
         // loads per thread and pass: the whole matrix in one burst up to K = 96 (a pass is one L2 round trip)
-        constexpr int SU = RT == 1 ? 8 : RT == 2 ? 16 : RT == 3 ? 24 : 16;
         const int cshift = 31 - __builtin_clz((unsigned)C);
 #pragma unroll 1
         for (int base = 0; base < nv; base += NT * SU) {
@@ -195,6 +190,47 @@ __global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restri
             }
         }
     }
+}
+
+// NW waves per block split the channels: NLD = C / (2 NW) k-steps per wave.
+template <typename T, int RT, int NLD, bool BUILD, int NW>
+__global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
+                                                          int64_t wn_stride, const int64_t* __restrict__ labels,
+                                                          int way, int K, int C, int P, int base,
+                                                          float* __restrict__ logits, float* __restrict__ bin,
+                                                          WnBuild wb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int n = blockIdx.y, p0 = blockIdx.x * CL_TP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ldw = C + 1;
+
+    constexpr int NT = 64 * NW;
+    const int cper = C / NW;                       // channels per wave
+    const int cbeg = wave * cper;
+    const int pa = p0 + 2 * j;
+    const bool fast = (p0 + CL_TP <= P);           // block-uniform: only the last tile of an episode is partial
+    const T* fq = Fq + (int64_t)n * C * P;
+    // The streamed operand first: up to 64 channels (32 k-steps, 16 KB per wave) of Fq go in flight
+    // before anything else, so the Wn staging below hides under their latency.
+    STAMP(0);
+    constexpr int chunk = 2 * NLD;                 // channels per pass of this wave (== cper: C is 64 or 256)
+    float b0[NLD], b1[NLD];
+#ifdef DENET_DIAG_NO_FQ
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) { b0[u] = (float)u; b1[u] = 1.f; }
+#else
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) load2<T, true>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) load2<T, false>(fq + (int64_t)(cbeg + 2 * u + hh) * P, pa, P, b0[u], b1[u]);
+    }
+#endif
+
+    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : RT == 3 ? 24 : 16;
+    stage_wn<BUILD, NT, NLD * NW / 8, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
     __syncthreads();
     STAMP(1);
     if constexpr (BUILD) {
@@ -325,6 +361,186 @@ __global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------
+// K > 32 (COCO: K = 81): Wn[n] is 83 KB of LDS, one block per CU, and the layout above re-stages it for every
+// 64 positions (C3: 6 us of a block's 19 in staging, 3.6 in the cross-wave reduction, the MFMA pipe busy a
+// third of the time).  Here a block keeps Wn[n] resident for FOUR position tiles: wave w owns tile 4*g + w and
+// ALL channels, so nothing is reduced across waves and no partial tile goes through LDS; Fq is streamed in
+// chunks of 32 channels, the next chunk's loads in flight under the current chunk's MFMAs (96 of them, ~6k
+// cycles); logits are stored straight from the accumulators (a row of a wave store = 256 contiguous bytes) and
+// the binary logits come from a per-lane top-2 scan of the accumulators merged across the two lane halves.
+// ---------------------------------------------------------------------------
+#define CLW_NLD 16         // k-steps (pairs of channels) per chunk
+template <typename T, int RT, bool BUILD, int CJ>
+__global__ __launch_bounds__(256) void classify_fwd_wide_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
+                                                               int64_t wn_stride, const int64_t* __restrict__ labels,
+                                                               int way, int K, int P, int base,
+                                                               float* __restrict__ logits, float* __restrict__ bin,
+                                                               WnBuild wb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = 64 * CJ;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ldw = C + 1;
+    const int ntile = (P + CL_TP - 1) / CL_TP;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool active = tile < ntile;
+    const int p0 = (active ? tile : ntile - 1) * CL_TP;
+    const int pa = p0 + 2 * j;
+    const T* fq = Fq + (int64_t)n * C * P;
+
+    typedef typename Raw2<T>::type raw_t;
+    const int pc = max(min(pa, P - 2), 0), sh = pa - pc;
+    raw_t bA[CLW_NLD], bB[CLW_NLD];
+    // raw loads only; __builtin_amdgcn_sched_barrier keeps the compiler from sinking them to their uses
+    auto load_chunk = [&](int c, raw_t (&x)[CLW_NLD]) {
+#pragma unroll
+#ifdef DENET_DIAG_NO_FQ
+        for (int u = 0; u < CLW_NLD; ++u) x[u] = raw_t{};
+#else
+        for (int u = 0; u < CLW_NLD; ++u) x[u] = raw2_load(fq + (int64_t)(c + 2 * u + hh) * P, pc);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    STAMP(0);
+    load_chunk(0, bA);                             // in flight under the Wn staging
+
+    constexpr int SUc = RT == 2 ? 16 : RT == 3 ? 24 : 16;
+    stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
+    // rows K .. 32*RT-1 of the LDS image are zeros: the MFMA A operand needs no row mask (a select between the
+    // LDS read and the MFMA also re-writes a register the previous MFMA may still be reading)
+    for (int i = K * ldw + tid; i < 32 * RT * ldw; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    if constexpr (BUILD) {
+        float* dst = wb.Wn_out + (int64_t)n * K * C;
+        for (int k = blockIdx.x; k < K; k += gridDim.x)
+            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
+    }
+    if (!active) return;                           // (no barrier below this line)
+    STAMP(1);
+
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][t][e] = 0.f;
+    int arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = (32 * rt + j) * ldw;
+    auto mfma_chunk = [&](int c, const raw_t (&x)[CLW_NLD]) {
+        // the chunk's A operands (RT x 16 LDS words per lane) in one burst, then MFMAs back to back: with one
+        // wave per SIMD an LDS read issued right before its MFMA exposes its latency every other k-step
+        float av[CLW_NLD][RT];
+#pragma unroll
+        for (int u = 0; u < CLW_NLD; ++u)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) av[u][rt] = sm[arow[rt] + c + 2 * u + hh];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CLW_NLD; ++u) {
+            float x0, x1;
+            raw2_get(x[u], sh, x0, x1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][rt], x0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][rt], x1, acc[rt][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int CH = 2 * CLW_NLD;                // channels per chunk
+#pragma unroll 1
+    for (int c = 0; c < C; c += 2 * CH) {
+        load_chunk(c + CH, bB);                    // C is a multiple of 64: chunk pairs are always whole
+        mfma_chunk(c, bA);
+        load_chunk(c + 2 * CH < C ? c + 2 * CH : 0, bA);     // (the last prefetch re-reads chunk 0: unused)
+        mfma_chunk(c + CH, bB);
+    }
+
+    STAMP(2);
+    // ---- logits: straight from the accumulators ----
+    float* lg = logits + (int64_t)n * K * P;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (row < K) {
+                float* dst = lg + (int64_t)row * P + pa;
+                if (pa + 1 < P) *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{acc[rt][0][e], acc[rt][1][e]};
+                else if (pa < P) dst[0] = acc[rt][0][e];
+            }
+        }
+    STAMP(3);
+    if (bin == nullptr) return;
+
+    // ---- binary logits (utils/operations.py:327-337) ----
+    // per lane and position: the largest and the second largest entry over this lane's rows (ties count: two
+    // equal maxima give m2 == m1), then merged across the two lane halves.  max over k != lab is then
+    // m2 if the label row holds the maximum (fg == m1), else m1 -- no row index needed.
+    float m1[2] = {-INFINITY, -INFINITY}, m2[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = row < K ? acc[rt][t][e] : -INFINITY;
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);       // second largest of {m1 >= m2, v}
+                m1[t] = fmaxf(m1[t], v);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float o1 = __shfl_xor(m1[t], 32, 64), o2 = __shfl_xor(m2[t], 32, 64);
+        const float hi = fmaxf(m1[t], o1), lo = fminf(m1[t], o1);
+        m2[t] = fmaxf(lo, fmaxf(m2[t], o2));
+        m1[t] = hi;
+    }
+    for (int jw = 0; jw < way; ++jw) {
+        const int64_t lab64 = labels[(int64_t)n * way + jw];
+        const bool labok = lab64 >= 0 && lab64 < K;
+        const int lab = labok ? (int)lab64 : 0;
+        // the accumulator that holds row `sel`: (rt, e) are wave-uniform, the lane half is (row >> 2) & 1
+        auto pick = [&](int sel, float (&out)[2]) {
+            const int r = sel & 31, idx = (sel >> 5) * 16 + (r & 3) + 4 * (r >> 3), half = (r >> 2) & 1;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (idx == rt * 16 + e) { v0 = acc[rt][0][e]; v1 = acc[rt][1][e]; }     // uniform branch
+            const float w0 = __shfl_xor(v0, 32, 64), w1 = __shfl_xor(v1, 32, 64);
+            out[0] = hh == half ? v0 : w0;
+            out[1] = hh == half ? v1 : w1;
+        };
+        float fg[2], outb[2];
+        pick(lab, fg);
+        if (base) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) outb[t] = (labok && fg[t] == m1[t]) ? m2[t] : m1[t];
+        } else {
+            pick(0, outb);
+        }
+        if (hh == 0) {
+            float* dst = bin + ((int64_t)(n * way + jw) * 2) * P + pa;
+            const float f0 = labok ? fg[0] : 0.f, f1 = labok ? fg[1] : 0.f;
+            if (pa + 1 < P) {
+                *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{outb[0], outb[1]};
+                *reinterpret_cast<f32x2_u*>(dst + P) = f32x2_u{f0, f1};
+            } else if (pa < P) {
+                dst[0] = outb[0];
+                dst[P] = f0;
+            }
+        }
+    }
+    STAMP(4);
+}
+
+// ---------------------------------------------------------------------------
 // K3e stand-alone: get_binary_logits on an existing logits tensor (utils/operations.py:313-338)
 // and the batch mean of extended weights for mode='deploy' (model/common.py:369-372).
 // ---------------------------------------------------------------------------
@@ -375,6 +591,28 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                                int64_t way, int64_t K, int64_t C, int64_t P, int base, float* logits, float* bin,
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
+    if (RT >= 2) {
+        // K > 32: Wn[n] resident for four position tiles per block (classify_fwd_wide_kernel)
+        const size_t ldsw = (size_t)32 * RT * (C + 1) * 4;          // rows K .. 32*RT-1 are zero padding
+        if (ldsw > 160 * 1024 || RT > 4) return DENET_E_UNSUPPORTED;
+        const int ntile = (int)((P + CL_TP - 1) / CL_TP);
+        dim3 gridw((unsigned)((ntile + 3) / 4), (unsigned)N), blockw(256);
+#define CL_WIDE(R, J)                                                                                         \
+    {                                                                                                         \
+        int rc = set_lds(classify_fwd_wide_kernel<T, R, BUILD, J>, ldsw);                                     \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((classify_fwd_wide_kernel<T, R, BUILD, J>), gridw, blockw, ldsw, st, Fq, Wn, wn_stride, \
+                           labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
+    }
+        switch (RT) {
+            case 2: if (C == 64) CL_WIDE(2, 1) else CL_WIDE(2, 4) break;
+            case 3: if (C == 64) CL_WIDE(3, 1) else CL_WIDE(3, 4) break;
+            default: if (C == 64) CL_WIDE(4, 1) else CL_WIDE(4, 4) break;
+        }
+#undef CL_WIDE
+        DENET_CHECK_LAUNCH();
+        return DENET_OK;
+    }
     // K <= 32: eight waves per block (32 MFMA k-steps per wave instead of 64; there is one block per CU
     // at batch 8, so the extra waves are free); larger K keeps four (the partial tiles must fit in LDS)
     const int NW = RT == 1 ? 8 : 4;
@@ -389,13 +627,7 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
         hipLaunchKernelGGL((classify_fwd_kernel<T, R, L, BUILD, W>), grid, block, lds, st, Fq, Wn, wn_stride, \
                            labels, (int)way, (int)K, (int)C, (int)P, base, logits, bin, wb);                \
     }
-    switch (RT) {
-        case 1: if (C == 64) CL_FWD3(1, 4, 8) else CL_FWD3(1, 16, 8) break;
-        case 2: if (C == 64) CL_FWD3(2, 8, 4) else CL_FWD3(2, 32, 4) break;
-        case 3: if (C == 64) CL_FWD3(3, 8, 4) else CL_FWD3(3, 32, 4) break;
-        case 4: if (C == 64) CL_FWD3(4, 8, 4) else CL_FWD3(4, 32, 4) break;
-        default: return DENET_E_UNSUPPORTED;
-    }
+    if (C == 64) CL_FWD3(1, 4, 8) else CL_FWD3(1, 16, 8)
 #undef CL_FWD3
     DENET_CHECK_LAUNCH();
     return DENET_OK;
