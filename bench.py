@@ -84,9 +84,10 @@ def pmc_traffic(kernel: str, config: str, episodes: int):
             d = json.load(f)
     except (OSError, ValueError):
         return None
-    if d.get("config") != config or d.get("episodes") != episodes:
+    run = d.get("runs", {}).get(f"{config}/{episodes}")
+    if run is None:
         return None
-    return d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    return run.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def main():

@@ -26,7 +26,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-NAMES = [("upsample_loss_pair_kernel", "loss_pair_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"),
+NAMES = [("wce_chain_pair_kernel", "loss_pair_fwd"), ("upsample_loss_pair_kernel", "loss_pair_fwd"),
+         ("wce_chain_kernel", "wce_fwd"), ("focal_kernel", "focal_fwd"), ("classify_fwd_wide_kernel", "classify_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"),
          ("head_bwd_mid_kernel", "bwd_chain_dfq"), ("head_bwd_tail_kernel", "bwd_params_dfs"),
          ("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_pool_fwd"),
          ("proto_extend_fwd_kernel", "proto_extend_fwd"), ("gate_proj_kernel", "proto_extend_fwd"), ("classify_fwd_kernel", "classify_fwd"),
@@ -38,9 +39,29 @@ NAMES = [("upsample_loss_pair_kernel", "loss_pair_fwd"), ("head_bwd_dwn_kernel",
          ("head_bwd_tail_kernel", "head_bwd_tail")]
 
 
-# read-side correction factor per kernel (see module docstring); anything else: 1, flagged uncalibrated
-READ_FACTOR = {"masked_pool_fwd": 2, "masked_sum_bwd": 2, "pe_bwd_reduce": 2, "proto_extend_fwd": 2,
-               "wce_fwd": 1, "focal_fwd": 1, "wce_fwd_nograd": 1, "mask_resize": 1, "loss_pair_fwd": 1}
+# Read-side correction factor per kernel = FETCH_SIZE under-count of its dominant load width, from
+# scripts/diag/fetch_calib.hip (profiles/r2_fetch_calibration.txt: a 1 GiB stream read with 4-, 8- and 16-byte
+# loads per lane).  The width of each kernel's streamed loads is read off its ISA (scripts/isa_scan.py):
+#   16 B/lane: masked_pool_fwd (Fs), bwd_dwn (Fq tiles, dlog slabs as dwords), pe_bwd_reduce, proto_extend_fwd
+#    8 B/lane: classify_fwd (Fq pairs), loss_pair_fwd / wce_fwd / focal_fwd (int64 labels), mask_resize
+#    4 B/lane: bwd_chain_dfq (slab rows), bwd_params_dfs (mask rows; its 80 MB are WRITES)
+LOAD_WIDTH = {"masked_pool_fwd": 16, "masked_sum_bwd": 16, "pe_bwd_reduce": 16, "proto_extend_fwd": 16,
+              "bwd_dwn": 16, "classify_bwd": 16,
+              "classify_fwd": 8, "loss_pair_fwd": 8, "wce_fwd": 8, "focal_fwd": 8, "wce_fwd_nograd": 8, "mask_resize": 8,
+              "bwd_chain_dfq": 4, "bwd_params_dfs": 4, "loss_finalize": 4}
+WIDTH_FACTOR = {4: 1.0, 8: 1.0, 16: 2.0}          # overwritten from profiles/r2_fetch_calibration.json if present
+
+
+def load_calibration():
+    path = os.path.join(ROOT, "profiles", "r2_fetch_calibration.json")
+    if os.path.exists(path):
+        d = json.load(open(path))
+        for w, f in d.get("factor_by_width", {}).items():
+            WIDTH_FACTOR[int(w)] = float(f)
+
+
+def read_factor(k):
+    return WIDTH_FACTOR.get(LOAD_WIDTH.get(k, 0), 1.0)
 
 
 def short(name):
@@ -92,23 +113,28 @@ def main():
                          f"pct={float(r['Percentage']):6.2f}")
     traffic = None
     if a.fetch_dir and a.write_dir:
+        load_calibration()
         fe, wr = pmc_mean(a.fetch_dir, "FETCH_SIZE"), pmc_mean(a.write_dir, "WRITE_SIZE")
-        traffic = {"config": a.config, "episodes": a.episodes,
-                   "note": "hbm_bytes_per_launch = f*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB counters); f = 2 for "
-                           "16-B-per-lane streams (gfx950 FETCH_SIZE tallies 128-B requests at 64 B: "
-                           "MI355X_MICROARCH.md), f = 1 for 8-B-per-lane streams; see scripts/pmc_summary.py",
-                   "kernels": {}}
+        path = os.path.join(out, "pmc_traffic.json")
+        allruns = json.load(open(path)) if os.path.exists(path) else {}
+        if "runs" not in allruns:
+            allruns = {"runs": {}}
+        allruns["note"] = ("hbm_bytes_per_launch = f*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB counters, separate --pmc "
+                           "passes); f = the FETCH_SIZE under-count of the kernel's streamed load width, calibrated in "
+                           "profiles/r2_fetch_calibration.json (scripts/diag/fetch_calib.hip); see scripts/pmc_summary.py")
+        traffic = {"config": a.config, "episodes": a.episodes, "tag": a.tag, "kernels": {}}
         lines.append("")
         lines.append("PMC (mean per launch): kernel, FETCH_SIZE KiB (raw), WRITE_SIZE KiB (raw), corrected HBM bytes")
         for k in sorted(set(fe) | set(wr)):
             f_, w_ = fe.get(k, 0.0), wr.get(k, 0.0)
-            fac = READ_FACTOR.get(k, 1)
+            fac = read_factor(k)
             hb = int(fac * f_ * 1024 + w_ * 1024)
             traffic["kernels"][k] = {"fetch_size_kib_raw": round(f_, 2), "write_size_kib_raw": round(w_, 2),
-                                     "read_factor": fac, "calibrated": k in READ_FACTOR,
-                                     "hbm_bytes_per_launch": hb}
+                                     "read_factor": fac, "load_width": LOAD_WIDTH.get(k),
+                                     "calibrated": k in LOAD_WIDTH, "hbm_bytes_per_launch": hb}
             lines.append(f"{k:24s} fetch={f_:12.2f} write={w_:12.2f} hbm_bytes={hb}")
-        json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+        allruns["runs"][f"{a.config}/{a.episodes}"] = traffic
+        json.dump(allruns, open(path, "w"), indent=1)
     open(os.path.join(out, f"{a.tag}_summary.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
