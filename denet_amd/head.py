@@ -40,7 +40,8 @@ def freeze_weights(module):
 class MaskedAveragePooling(nn.Module):
     """model/common.py:149-200.  Inside WeightEstimator only its ``linear``
     parameters are used (the pooling is fused into kernels K1/K2); called on its
-    own it runs the HIP masked-sum kernel plus the 1x1 projection (forward only)."""
+    own it runs the HIP mask-resize and masked-sum kernels plus the 1x1 projection,
+    differentiable w.r.t. the embedding and ``linear`` as in the reference."""
 
     def __init__(self, depth=None, project=True):
         super().__init__()
@@ -49,20 +50,20 @@ class MaskedAveragePooling(nn.Module):
         if project and depth is not None:
             self.linear = nn.Conv2d(in_channels=depth, out_channels=depth, kernel_size=1)
 
-    @torch.no_grad()
     def forward(self, embedding, mask, pooling=True, eps=1e-3):
         B, c, h, w = embedding.shape
         m, cnt = ops.mask_resize(mask, h, w)
         if not pooling:
             return m.reshape(B, 1, h, w) * embedding
-        S = ops.masked_sum(embedding, m)
+        S = ops.MaskedSumFunction.apply(embedding, m)
         proto = (S / (cnt.unsqueeze(1) + eps)).reshape(B, c, 1, 1)
         return self.linear(proto) if self.linear is not None else proto
 
 
 class GAM(nn.Module):
     """Guided attention module, model/common.py:211-246.  Inside WeightEstimator the gate is
-    fused into kernel K2; called on its own this is a forward-only convenience."""
+    fused into kernel K2; called on its own it is differentiable like the reference's module (masked mean on
+    the HIP kernels, gate and the channel-wise product as stock modules)."""
 
     def __init__(self, in_channels, drop_rate=0.5):
         super().__init__()
@@ -81,12 +82,11 @@ class GAM(nn.Module):
         m, _ = ops.mask_resize(mask, h, w)
         return m.reshape(B, 1, h, w) * embedding
 
-    @torch.no_grad()
     def forward(self, *x):
         Fs, Ys = x
         B, c, h, w = Fs.shape
         m, _ = ops.mask_resize(Ys, h, w)
-        att = (ops.masked_sum(Fs, m) / float(h * w)).reshape(B, c, 1, 1)
+        att = (ops.MaskedSumFunction.apply(Fs, m) / float(h * w)).reshape(B, c, 1, 1)
         return self.gate(att) * Fs
 
 

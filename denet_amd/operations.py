@@ -26,10 +26,11 @@ def depart_first_dim(x: torch.Tensor, dims):
 
 def get_binary_logits(logits_full: torch.Tensor, label: torch.Tensor, base: bool = True):
     """(N, K, h, w), (N) -> (N, 2, h, w): channel 0 = max over the other K-1 rows (row 0 when
-    base=False), channel 1 = row `label`.  utils/operations.py:313-338.  Forward only: the
-    reference never back-propagates through the binary logits (trainer/trainers.py:972-974)."""
+    base=False), channel 1 = row `label`.  utils/operations.py:313-338.  The result stays in the autograd
+    graph, but a backward pass through it raises: the reference never back-propagates through the binary
+    logits (trainer/trainers.py:972-974) and no gradient kernel exists for them."""
     N = logits_full.shape[0]
-    return ops.binary_logits(logits_full.detach(), label.reshape(N, 1), way=1, base=base)
+    return ops.BinaryLogitsFunction.apply(logits_full, label.reshape(N, 1), 1, base)
 
 
 def process_nway(Yq_pre: torch.Tensor, way: int):

@@ -294,6 +294,37 @@ class EstimatorFunction(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class MaskedSumFunction(torch.autograd.Function):
+    """S[b,c] = sum_p mask[b,p] * Fs[b,c,p] (kernel K1) with its rank-1 backward dFs = mask x dS (kernel K1b):
+    the differentiable piece behind the stand-alone MaskedAveragePooling / GAM modules (model/common.py:188-246)."""
+
+    @staticmethod
+    def forward(ctx, Fs, mask):
+        ctx.save_for_backward(mask)
+        ctx.fs_shape, ctx.fs_dtype = Fs.shape, Fs.dtype
+        return masked_sum(Fs, mask)
+
+    @staticmethod
+    def backward(ctx, dS):
+        (mask,) = ctx.saved_tensors
+        return masked_sum_bwd(mask, dS.contiguous().float(), ctx.fs_shape, ctx.fs_dtype), None
+
+
+class BinaryLogitsFunction(torch.autograd.Function):
+    """get_binary_logits (utils/operations.py:313-338) as a graph node: the forward is kernel K3e; a backward
+    through it raises instead of silently cutting the graph (the reference never back-propagates loss_p,
+    trainer/trainers.py:972-974, and no gradient kernel exists for it here)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, way, base):
+        return binary_logits(logits, labels, way=way, base=base)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("gradient through get_binary_logits is not implemented: the reference only "
+                                  "back-propagates loss_k (trainer/trainers.py:972-974)")
+
+
 class ExtendFunction(torch.autograd.Function):
     """WeightEstimator.extend(mode='training') alone (model/common.py:359-368):
     (Fs, weight, W1, b1, W2, b2, Wl, bl | Ys, labels, masks) -> (Wn [N,K,C], proto [N*way,C])."""

@@ -264,3 +264,38 @@ def test_process_nway_and_nway_fusion_match_reference(dev, golden_dir):
     assert [bi.inter[k] for k in bi.inter] == z["out:nway_inter"].tolist()
     assert [bi.union[k] for k in bi.union] == z["out:nway_union"].tolist()
     assert bi.mean_iou() == float(z["out:nway_mean"]) and bi.mean_bf_iou() == float(z["out:nway_bf"])
+
+
+def test_standalone_gam_and_map_are_differentiable(dev):
+    """model/common.py:170-246: the reference's GAM / MaskedAveragePooling are ordinary differentiable modules
+    that other heads reuse; called on their own here they must carry gradients to the embedding and to their
+    parameters (oracle = the same lines on CPU autograd)."""
+    from denet_amd.head import GAM, MaskedAveragePooling
+    from oracle import denet_oracle as O
+    z, d, ep, params, gm, wm = load_case("eval_2way_3shot")
+    B = d["N"] * d["way"] * d["shot"]
+    Fm = ep["Fs"].float().reshape(B, d["c"], d["h"], d["w"])
+    Ym = ep["Ys"].reshape(B, d["H"], d["W"])
+    gam, mp = GAM(d["c"]).to(dev).eval(), MaskedAveragePooling(depth=d["c"]).to(dev)
+    sd = {k[4:]: v for k, v in params.items() if k.startswith("gam.")}
+    gam.load_state_dict(sd)
+    mp.load_state_dict({k[4:]: v for k, v in params.items() if k.startswith("map.")})
+    x = Fm.to(dev).requires_grad_(True)
+    out = mp(gam(x, Ym.to(dev)), Ym.to(dev))                    # gate * Fs -> masked average -> linear
+    out.square().sum().backward()
+    # oracle
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xc = Fm.clone().requires_grad_(True)
+    ref = O.masked_avg_pool_project(O.gate(O.gam_attention(xc, Ym), p) * xc, Ym, p)
+    ref.square().sum().backward()
+    assert_close(out.detach().cpu(), ref.detach(), 2e-5, "proto")
+    assert_close(x.grad.cpu(), xc.grad, 1e-4, "d embedding")
+    assert_close(mp.linear.weight.grad.cpu(), p["map.linear.weight"].grad, 1e-4, "d map.linear.weight")
+    assert_close(gam.gate[0].weight.grad.cpu(), p["gam.gate.0.weight"].grad, 1e-4, "d gam.gate.0.weight")
+    # the binary logits stay in the graph, and a backward through them fails loudly
+    from denet_amd.operations import get_binary_logits
+    lg = torch.randn(2, 5, 4, 4, device=dev, requires_grad=True)
+    b = get_binary_logits(lg, torch.tensor([1, 3], device=dev))
+    assert b.requires_grad
+    with pytest.raises(NotImplementedError):
+        b.sum().backward()
