@@ -288,8 +288,13 @@ class DENet(nn.Module):
     with 1024 channels (used by the tests and by synthetic-feature runs)."""
 
     def __init__(self, backbone="ResNet50", maximum_num_classes=21, depth=256, drop_rate=0.5,
-                 support_free=False, visualize=True):
+                 support_free=False, visualize=True, feature_dtype=torch.float32):
         super().__init__()
+        # feature_dtype (extension, SURVEY.md §8f N2): torch.bfloat16 makes the producer's tail run under
+        # bf16 autocast, so `features()` hands bf16 NCHW straight to the head's bf16 kernels (fp32
+        # accumulation inside) -- no fp32 feature map, no cast pass between producer and head
+        assert feature_dtype in (torch.float32, torch.bfloat16), 'feature_dtype must be float32 or bfloat16'
+        self.feature_dtype = feature_dtype
         if isinstance(backbone, str):
             assert backbone in ['ResNet50', 'DenseNet121'], 'get unsupported backbone "%s" for DENet.' % backbone
             backbone = _torchvision_backbone(backbone)
@@ -308,7 +313,12 @@ class DENet(nn.Module):
 
     def features(self, images):
         """backbone['layer3'] -> embedding -> deeplab_head (model/head/denet.py:60-62,71-73)."""
-        return self.deeplab_head(self.embedding(self.backbone(images)['layer3']), relu=True)
+        layer3 = self.backbone(images)['layer3']
+        if self.feature_dtype == torch.bfloat16 and layer3.is_cuda:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                f = self.deeplab_head(self.embedding(layer3), relu=True)
+            return f.to(torch.bfloat16).contiguous()        # (already bf16 under autocast: no copy)
+        return self.deeplab_head(self.embedding(layer3), relu=True)
 
     def forward(self, *x):
         Is, Ys, Iq, label = x

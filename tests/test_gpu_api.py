@@ -299,3 +299,45 @@ def test_standalone_gam_and_map_are_differentiable(dev):
     assert b.requires_grad
     with pytest.raises(NotImplementedError):
         b.sum().backward()
+
+
+def test_denet_bf16_features_from_the_producer(dev):
+    """N2: DENet(feature_dtype=bfloat16): the conv stack emits bf16 NCHW and the head's bf16 kernels consume it
+    (fp32 accumulate).  Parity: the oracle head fed the SAME bf16-rounded features (1e-3 on logits / parameter
+    gradients, 8e-3 on the feature gradient, which is rounded to bf16 on output), and one forward at the real
+    producer shape [*,1024,41,41] -> 256 channels at C2's batch."""
+    from denet_amd.head import DENet
+    from denet_amd.trainer import SyntheticBackbone, SyntheticEpisodes
+    from oracle import denet_oracle as O
+    torch.manual_seed(0)
+    m = DENet(backbone=SyntheticBackbone(), maximum_num_classes=21, feature_dtype=torch.bfloat16).to(dev).eval()
+    Is, Ys, Iq, Yq, cls, Ys_full, Yq_full = SyntheticEpisodes(1, 2, 1, 2, 21, 65, split='val').batch(0)
+    N, way, shot = Is.shape[:3]
+    Fs = m.features(Is.reshape(-1, *Is.shape[3:]).to(dev)).reshape(N, way, shot, 256, 9, 9)
+    Fq = m.features(Iq.to(dev))
+    assert Fs.dtype == torch.bfloat16 and Fq.dtype == torch.bfloat16 and Fq.is_contiguous()
+    Fq_l, Fs_l = Fq.detach().clone().requires_grad_(True), Fs.detach().clone().requires_grad_(True)
+    full, binl = m.estimator.forward_with_binary(Fq_l, Fs_l, Ys.to(dev), cls.to(dev))
+    assert full.dtype == torch.float32
+    g = torch.Generator().manual_seed(3)
+    cot = torch.randn(full.shape, generator=g)
+    (full * cot.to(dev)).sum().backward()
+    # oracle on the same bf16-rounded features
+    state = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.estimator.state_dict().items()}
+    Fq_c, Fs_c = Fq.detach().float().cpu().requires_grad_(True), Fs.detach().float().cpu().requires_grad_(True)
+    ref_full, ref_bin, _ = O.head_forward(Fq_c, Fs_c, Ys, cls, state)
+    (ref_full * cot).sum().backward()
+    assert rel_err(full.detach().cpu(), ref_full.detach()) < 1e-3
+    assert rel_err(binl.detach().cpu(), ref_bin.detach()) < 1e-3
+    assert Fq_l.grad.dtype == torch.bfloat16
+    assert rel_err(Fq_l.grad.float().cpu(), Fq_c.grad) < 8e-3 and rel_err(Fs_l.grad.float().cpu(), Fs_c.grad) < 8e-3
+    for k, p in m.estimator.named_parameters():
+        assert rel_err(p.grad.cpu(), state[k].grad) < 1e-3, k
+    # the real shape: 8 episodes, 1-way 5-shot, 321 x 321 images -> [*,1024,41,41] -> [*,256,41,41] bf16
+    Is8, Ys8, Iq8, _, cls8, _, _ = SyntheticEpisodes(1, 8, 1, 5, 21, 321, split='val').batch(0)
+    with torch.no_grad():
+        l3 = m.backbone(Iq8.to(dev))['layer3']
+        assert l3.shape == (8, 1024, 41, 41)
+        full8, bin8 = m(Is8.to(dev), Ys8.to(dev), Iq8.to(dev), cls8.to(dev))
+    assert full8.shape == (8, 21, 41, 41) and bin8.shape == (8, 2, 41, 41) and torch.isfinite(full8).all()
+    assert m.vis["hidden_Fq"].dtype == torch.bfloat16
