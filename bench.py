@@ -108,7 +108,13 @@ def main():
     ap.add_argument("--collective", action="store_true",
                     help="with one rank: still create the RCCL group and run the step's gradient all-reduce "
                          "(exercises the N > 1 code path on a one-GPU box)")
+    ap.add_argument("--train-mode", action="store_true",
+                    help="time the step with train-mode dropout generated inside the kernels (p = 0.5 at both "
+                         "sites, a new seed every step) instead of eval mode; the default run reports it beside "
+                         "the eval-mode value as `train_mode`")
     args = ap.parse_args()
+    if args.train_mode and args.graph:
+        raise SystemExit("--train-mode with --graph would replay one captured seed; run them separately")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,10 +163,17 @@ def main():
 
     # the step's buffers never change: bind the arguments once, so a step costs ~20 us of host time
     # (two library calls) instead of ~40 us of ctypes argument conversion
-    eng.bind_step(ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params)
+    # train mode: WeightEstimator's two dropouts (model/common.py:231,326), generated in the kernels from a seed
+    # the host advances every step (the library reads the struct at each call)
+    drop = _lib.Dropout(0x5EED0000 + rank, 0.5, 0.5)
+    bind_args = (ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params)
+    eng.bind_step(*bind_args, drop=drop if args.train_mode else None)
+    train_now = [args.train_mode]
 
     def step():
         st = torch.cuda.current_stream().cuda_stream if args.graph else stream     # capture runs on a side stream
+        if train_now[0]:
+            drop.seed += world
         eng.run_forward(st)
         eng.run_backward(0, st)
         if dist is not None:
@@ -253,6 +266,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same step in train mode (in-kernel dropout), timed the same way, reported beside the main line ----
+    train_line = None
+    if not args.train_mode and graph is None:
+        eng.bind_step(*bind_args, drop=drop)
+        train_now[0] = True
+        for _ in range(5):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el2 = time.perf_counter() - t2
+        if dist is not None:
+            t = torch.tensor([el2], dtype=torch.float64, device="cpu" if host_reduce else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        train_line = {"value": round(N * world * args.steps / el2, 1), "unit": "episodes/s",
+                      "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                      "dropout": "Philox4x32-10 in F2 / F3 / B2, p=0.5 gate and class weights, new seed per step",
+                      "loss_k": float(eng.losses[0].item())}
+        train_now[0] = False
+        eng.bind_step(*bind_args, drop=None)
+        step()                                   # eng.losses back to the eval-mode values reported below
+        torch.cuda.synchronize()
+
     probe_us = None
     if pairs:
         probe_us = statistics.mean(a.elapsed_ms(b) * 1e3 for a, b in pairs.values())
@@ -328,9 +371,10 @@ def main():
             "config": {"workload": f"{args.config}: {way}-way {shape.shot}-shot head fwd+bwd, K={shape.K}, "
                                    f"features {shape.c}x{shape.h}x{shape.w}, labels {shape.H}x{shape.W}",
                        "episodes_per_gpu": N, "global_batch": N * world, "parallelism": f"dp{world} (episode-sharded)",
-                       "graph_replay": bool(graph)},
+                       "graph_replay": bool(graph),
+                       "mode": "train (in-kernel dropout, p=0.5)" if args.train_mode else "eval (no dropout)"},
             "roofline": roofline, "step_roofline": step_roof, "hbm_stream_kernels": streams,
-            "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu,
+            "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu, "train_mode": train_line,
             "kernels_us": {k: round(v, 2) for k, v in breakdown.items()},
             "loss_k": losses[0], "loss_p": losses[1],
         }

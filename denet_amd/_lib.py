@@ -20,7 +20,7 @@ BWD_HAVE_FOCAL, BWD_NO_DFS, BWD_ONLY_DFS = 1, 2, 4      # denet_head_step_bwd fl
 # signature table: p = device pointer of any dtype (features, workspace; tensor / None),
 # F = device pointer to float32, L = device pointer to int64 (both checked against the tensor's dtype:
 # the kernels read raw memory, so a bf16 / half / int32 tensor would be misread without an error),
-# l = int64, i = int, f = float, h = host pointer (ctypes object / None)
+# l = int64, u = uint64, i = int, f = float, h = host pointer (ctypes object / None)
 # the trailing stream argument is appended automatically ("s").
 _SIGS = {
     "denet_mask_resize": "L" "lllll" "FF",
@@ -47,6 +47,9 @@ _SIGS = {
     "denet_binary_iou_counts_fused": "FL" "lllll" "L",
     "denet_head_step_fwd": "ppi" "LLLLF" "FFFFFFF" "FF" "lllllllll" "i" "FFF" "pl" "h",
     "denet_head_step_bwd": "piL" "FFF" "FF" "F" "lllllllll" "pp" "FFFFFFF" "Fi" "pl" "h",
+    "denet_head_step_train_fwd": "ppi" "LLLLF" "FFFFFFF" "FF" "h" "lllllllll" "i" "FFF" "pl" "h",
+    "denet_head_step_train_bwd": "piL" "FFF" "FF" "h" "F" "lllllllll" "pp" "FFFFFFF" "Fi" "pl" "h",
+    "denet_dropout_mask": "uifl" "F",
 }
 _NOSTREAM = {
     "denet_version": (ctypes.c_char_p, ""),
@@ -57,13 +60,22 @@ _NOSTREAM = {
     "denet_head_step_workspace": (ctypes.c_int64, "lllllllll"),
     "denet_upsample_loss_parts": (ctypes.c_int64, "llllli"),
 }
-_CT = {"p": ctypes.c_void_p, "F": ctypes.c_void_p, "L": ctypes.c_void_p, "l": ctypes.c_int64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
+_CT = {"p": ctypes.c_void_p, "F": ctypes.c_void_p, "L": ctypes.c_void_p, "l": ctypes.c_int64, "u": ctypes.c_uint64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
 
 
 class Probe(ctypes.Structure):
     """denet_probe_t (include/denet_hip.h)."""
     _fields_ = [("which", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("start", ctypes.c_void_p), ("stop", ctypes.c_void_p)]
+
+
+class Dropout(ctypes.Structure):
+    """denet_dropout_t (include/denet_hip.h): in-kernel train-mode dropout of the fused step.  The library
+    reads the struct during each call, so a bound step sees a `seed` changed in place."""
+    _fields_ = [("seed", ctypes.c_uint64), ("p_gate", ctypes.c_float), ("p_weight", ctypes.c_float)]
+
+
+DROPOUT_GATE, DROPOUT_WEIGHT = 1, 2                     # stream ids of denet_dropout_mask
 
 
 # the launches of the fused step (include/denet_hip.h, DENET_K_*)

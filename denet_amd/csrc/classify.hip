@@ -84,6 +84,7 @@ __device__ __forceinline__ void raw2_get(const unsigned v, int sh, float& a, flo
 struct WnBuild {
     const float *weight /*[K][C]*/, *weight_mask /*[N][K][C] or null*/, *proto_part /*[N*way][C/16][C]*/, *bl;
     float* Wn_out /*[N][K][C]*/;
+    DropGen wdrop;        // used where weight_mask is null (train-mode entry points); zero = off
 };
 
 // Stage Wn[n] -> LDS [K][C+1] (16-byte loads, all of a thread's loads issued before the first store); BUILD:
@@ -145,6 +146,14 @@ __device__ __forceinline__ void stage_wn(float* sm, const float* __restrict__ Wn
                 }
 #pragma unroll
                 for (int u = 0; u < SU; ++u) { v[u][0] *= m[u][0]; v[u][1] *= m[u][1]; v[u][2] *= m[u][2]; v[u][3] *= m[u][3]; }
+            } else if (BUILD && wb.wdrop.on) {
+                // generated under the weight loads' latency; element (n, k, c) = flat index 4 * (n * nv + i4)
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i4 = min(base + u * NT + tid, nv - 1);
+                    const f32x4 m = drop_mult4(wb.wdrop, DENET_DROP_WEIGHT, (unsigned)(n * nv + i4));
+                    v[u][0] *= m[0]; v[u][1] *= m[1]; v[u][2] *= m[2]; v[u][3] *= m[3];
+                }
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -654,12 +663,12 @@ extern "C" int denet_classify_fwd(const void* Fq, int feat_dtype, const float* W
 int denet_classify_build_fwd(const void* Fq, int feat_dtype, const float* weight, const float* weight_mask,
                              const float* proto_part, const float* bl, const int64_t* labels, int64_t N, int64_t way,
                              int64_t K, int64_t C, int64_t P, float* Wn_out, float* logits, float* logits_binary,
-                             void* stream) {
+                             const DropGen* wdrop, void* stream) {
     if (!Fq || !weight || !proto_part || !bl || !labels || !Wn_out || !logits || !logits_binary) return DENET_E_BADARG;
     if (!pos(N) || !pos(K) || !pos(C) || !pos(P) || !pos(way)) return DENET_E_BADARG;
     if (!c_ok(C) || K > 128 || N > 65535) return DENET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    WnBuild wb{weight, weight_mask, proto_part, bl, Wn_out};
+    WnBuild wb{weight, weight_mask, proto_part, bl, Wn_out, wdrop ? *wdrop : DropGen{0u, 0u, 0u, 1.f, 0}};
     if (feat_dtype == DENET_F32)
         return launch_classify_fwd<float, true>((const float*)Fq, nullptr, 0, labels, N, way, K, C, P, 1, logits,
                                                 logits_binary, st, wb);

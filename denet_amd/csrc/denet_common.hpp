@@ -102,6 +102,56 @@ template <> struct FeatIO<unsigned short> {
     static __device__ __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// ---- train-mode dropout generated inside the kernels ---------------------------------------------
+// F.dropout(p) of model/common.py:231 (gate) and :326 (class weights): multiplier 0 with probability p,
+// 1/(1-p) otherwise.  Counter-based Philox4x32-10 (Salmon et al., SC'11): key = seed, counter =
+// (element index / 4, stream id, 0, 0); one evaluation yields the multipliers of four consecutive
+// elements, so forward and backward regenerate the same values from (seed, index) and nothing but the
+// seed is kept between them.  A mask POINTER, where one is passed, always wins (injected-mask parity).
+#define DENET_DROP_GATE 1u
+#define DENET_DROP_WEIGHT 2u
+struct DropGen {
+    unsigned k0, k1;     // seed
+    unsigned thresh;     // drop iff r < thresh, thresh = round(p * 2^32)
+    float scale;         // 1 / (1 - p)
+    int on;              // 0: multiplier 1
+};
+__host__ __forceinline__ DropGen make_dropgen(unsigned long long seed, float p) {
+    DropGen g{(unsigned)seed, (unsigned)(seed >> 32), 0u, 1.f, 0};
+    if (p > 0.f && p < 1.f) {
+        const double t = (double)p * 4294967296.0 + 0.5;
+        g.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        g.scale = 1.f / (1.f - p);
+        g.on = 1;
+    }
+    return g;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned k0, unsigned k1, unsigned r[4]) {
+    unsigned c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+// multipliers of elements 4*i4 .. 4*i4+3 of stream `stream`
+__device__ __forceinline__ f32x4 drop_mult4(const DropGen& g, unsigned stream, unsigned i4) {
+    unsigned r[4];
+    philox4x32_10(i4, stream, g.k0, g.k1, r);
+    return f32x4{r[0] < g.thresh ? 0.f : g.scale, r[1] < g.thresh ? 0.f : g.scale,
+                 r[2] < g.thresh ? 0.f : g.scale, r[3] < g.thresh ? 0.f : g.scale};
+}
+// multiplier of element idx
+__device__ __forceinline__ float drop_mult1(const DropGen& g, unsigned stream, unsigned idx) {
+    unsigned r[4];
+    philox4x32_10(idx >> 2, stream, g.k0, g.k1, r);
+    const unsigned lo = (idx & 1u) ? r[1] : r[0], hi = (idx & 1u) ? r[3] : r[2];
+    return ((idx & 2u) ? hi : lo) < g.thresh ? 0.f : g.scale;
+}
+
 // Raise a kernel's dynamic-LDS limit above the 48 KiB default (host side, cached per kernel so
 // steady-state launches make no runtime call besides the launch itself).  Defined in api.hip.
 int denet_ensure_dynamic_lds(const void* kernel, size_t bytes);

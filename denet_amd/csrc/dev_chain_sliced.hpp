@@ -35,6 +35,7 @@ struct GateProjArgs {
     const float *pre1_part /*[B][NSL][C]*/, *S, *cnt, *b1, *W2, *b2, *Wl, *gate_mask;
     int shot;
     float *hidden, *gate, *pool /*[B][C]*/, *proto_part /*[G][NSL][C]*/;
+    DropGen gdrop;        // used where gate_mask is null (train-mode entry points); zero = off
 };
 #define SC_GP_LDS(C) ((size_t)(8 * (C) + 16) * 4)
 
@@ -66,7 +67,8 @@ __device__ __forceinline__ void gate_proj_body(const GateProjArgs& a, int grp, i
     for (int s = 0; s < NS; ++s) {
         const int64_t b = b0 + min(s, ns - 1);
         sS[s] = a.S[b * C + q];
-        sG[s] = a.gate_mask ? a.gate_mask[b * C + q] : 1.f;
+        sG[s] = a.gate_mask ? a.gate_mask[b * C + q]
+                            : (a.gdrop.on ? drop_mult1(a.gdrop, DENET_DROP_GATE, (unsigned)(b * C + q)) : 1.f);
         sC[s] = a.cnt[b] + SC_EPS;
     }
     // hidden = relu(b1 + W1 att): sum of the pooling kernel's split-K partials, every image of the group
@@ -144,6 +146,7 @@ struct ChainMidArgs {
     const int64_t* labels;
     int n_part, way, shot, K;
     float *u2 /*dz [B][C]*/, *u3 /*dproto [B][C]*/, *dpool /*[G][C]*/, *dh_part /*[B][NSL][C]*/;
+    DropGen gdrop;        // as in GateProjArgs: regenerates the forward's gate multipliers
 };
 #define SC_CM_LDS ((size_t)(64 + 16 * 8) * 4)
 
@@ -177,6 +180,7 @@ __device__ __forceinline__ void chain_mid_bwd_body(const ChainMidArgs& a, int gr
         const float den = a.cnt[b0 + fs] + SC_EPS;
         fz = a.S[gi] / den * g * (1.f - g);
         if (a.gate_mask) fz *= a.gate_mask[gi];
+        else if (a.gdrop.on) fz *= drop_mult1(a.gdrop, DENET_DROP_GATE, (unsigned)gi);
     }
     // dproto = dWn[n, label_j] / shot for every shot (mean backward), if this way owns the row
     const int64_t* lab = a.labels + (int64_t)n * way;

@@ -239,6 +239,277 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// K3b for K > 32 in the fused step: PERSISTENT blocks.  A block = (episode n, group of consecutive
+// position tiles, role) with 8 waves, one 32-channel tile per wave (C = 256):
+//   role DWN: the wave's dWn accumulators (RT x 16 registers) stay resident over the group's tiles and ONE
+//             slab per group is written, so n_part = groups per episode (6 at C3, 15 at C5) instead of
+//             tiles per episode (27 / 103): the slab traffic of this kernel and of its consumers (B2's
+//             dproto and dweight) shrinks by that factor;
+//   role DFQ: the wave's Wn^T fragments (RT x 16 registers) are loaded once per block, not once per tile.
+// dL = scale * (dlog_a + dlog_b) of tile t+1 is fetched into registers and the Fq tile of t+1 requested
+// while the MFMAs of tile t run (all loads unconditional: the last iteration re-requests its own tile), then
+// stored to the other of two LDS buffers: one barrier per tile.  Same arithmetic order per output element
+// as classify_bwd_body within a tile; across tiles the slab sum order changes (tiles of a group are
+// accumulated in the MFMA accumulators, groups in B2), which the element-wise tolerance of the tests covers.
+// ---------------------------------------------------------------------------
+#define CLW_BWD_NW 8
+#define CLW_LD 68         // dL row stride: 16-byte rows, conflict-free 16-byte reads down a column of rows
+#define CLW_DL(RT) ((RT) * 32 * CLW_LD)                                  // floats: dL [RT*32][CLW_LD], rows >= K zero
+#define CLW_BWD_LDS(RT) ((size_t)(2 * CLW_DL(RT) + CLW_BWD_NW * 32 * CL_TS) * 4)
+
+// diagnostic builds (scripts/diag/bwd_wide_stamps.hip): phase stamps of thread 0 of block (n 0, group 0) of one role
+#ifdef DENET_STAMPS
+#ifndef DENET_STAMP_ROLE_DWN
+#define DENET_STAMP_ROLE_DWN 1
+#endif
+#define WSTAMP(i) do { if (n == 0 && grp == 0 && threadIdx.x == 0 && DWN == (bool)(DENET_STAMP_ROLE_DWN)) g_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
+
+template <typename T, int RT, bool DWN>
+__device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int n, int grp, float* sm) {
+#ifdef DENET_DIAG_BW_ONLYDWN
+    if (!DWN) return;
+#endif
+#ifdef DENET_DIAG_BW_ONLYDFQ
+    if (DWN) return;
+#endif
+    const T* __restrict__ Fq = reinterpret_cast<const T*>(g.Fq);
+    const float* __restrict__ dlog_a = g.dlog_a;
+    const float* __restrict__ dlog_b = g.dlog_b;
+    T* __restrict__ dFq = reinterpret_cast<T*>(g.dFq);
+    float* __restrict__ dWn_part = g.dWn_part;
+    const int K = g.K, C = g.C, P = g.P, ngrp = g.n_part;
+    constexpr int NT = CLW_BWD_NW * 64, NL = RT * 4, NA = RT * 16;
+    const int ntile = (P + CL_TP - 1) / CL_TP;
+    const int t0 = (int)((int64_t)grp * ntile / ngrp), t1 = (int)((int64_t)(grp + 1) * ntile / ngrp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int KP = (K + 1) & ~1;
+    const float* wn = g.Wn + (int64_t)n * K * C;
+    const int ct = wave;
+    const bool have = ct < (C >> 5);               // C = 64: waves 2.. only help with the staging
+    const int r4 = lane >> 4, c16 = lane & 15;
+    float* dl0 = sm;
+    float* dl1 = sm + CLW_DL(RT);
+    float* tsm = sm + 2 * CLW_DL(RT) + wave * 32 * CL_TS;
+    // rows K .. RT*32-1 of both buffers stay zero: the MFMA row tiles read them without a guard
+    for (int idx = K * CLW_LD + tid; idx < RT * 32 * CLW_LD; idx += NT) { dl0[idx] = 0.f; dl1[idx] = 0.f; }
+
+    const bool have_b = dlog_b != nullptr;
+    const float* __restrict__ dlb = have_b ? dlog_b : dlog_a;
+    auto load_dl = [&](int tile, float (&va)[NL], float (&vb)[NL]) {
+#ifdef DENET_DIAG_BW_NODL
+        if (tile != t0) return;
+#endif
+        const int p0 = tile * CL_TP;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = u * NT + tid;
+            const int k = idx >> 6, p = p0 + (idx & 63);
+            const bool ok = k < K && p < P;
+            const int64_t gi = ((int64_t)n * K + min(k, K - 1)) * P + min(p, P - 1);
+            const float xa = dlog_a[gi];
+            const float xb = dlb[gi];                  // no branch around a load: dlb = dlog_a when dlog_b is null
+            va[u] = ok ? xa : 0.f;
+            vb[u] = (ok && have_b) ? xb : 0.f;
+        }
+    };
+    auto store_dl = [&](float* buf, const float (&va)[NL], const float (&vb)[NL], float sc) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = u * NT + tid;
+            if ((idx >> 6) < K) buf[(idx >> 6) * CLW_LD + (idx & 63)] = (va[u] + vb[u]) * sc;
+        }
+    };
+    auto load_raw = [&](int tile, f32x4 (&raw)[8]) {
+        const int pb = tile * CL_TP + 4 * c16;
+        const bool fast = (tile + 1) * CL_TP <= P;
+        const int cc = min(ct, (C >> 5) - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const T* rowp = Fq + ((int64_t)n * C + cc * 32 + 4 * i + r4) * P;
+            if (fast) {
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)rowp + pb);
+                    raw[i] = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    const u16x2_u v0 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb);
+                    const u16x2_u v1 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb + 2);
+                    raw[i] = f32x4{bf16_to_f32(v0[0]), bf16_to_f32(v0[1]), bf16_to_f32(v1[0]), bf16_to_f32(v1[1])};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = FeatIO<T>::load(rowp + min(pb + e, P - 1));
+                    raw[i][e] = (pb + e < P) ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto turn = [&](const f32x4 (&raw)[8], float (&dst)[32]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(tsm + (4 * i + r4) * CL_TS + 4 * c16) = raw[i];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tsm + j * CL_TS + 32 * hh + 4 * m);
+            dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
+        }
+    };
+
+    // everything this block needs first is requested before the first wait
+    float va[NL], vb[NL];
+    f32x4 raw[8];
+    float av[DWN ? 1 : NA];
+    WSTAMP(0);
+    load_dl(t0, va, vb);
+    if constexpr (DWN) {
+        load_raw(t0, raw);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int kk = 2 * u + hh;
+            const float v = wn[(int64_t)min(kk, K - 1) * C + min(ct, (C >> 5) - 1) * 32 + j];
+            av[u] = kk < K ? v : 0.f;
+        }
+    }
+    float sc;
+    if (g.part_k != nullptr) {
+        sc = 1.f / ((float)g.N * episode_den(g.part_k, g.parts_k, n));
+        if (g.scale_out != nullptr && grp == 0 && tid == 0) g.scale_out[n] = sc;
+    } else {
+        sc = g.scale ? g.scale[n] : 1.f;
+    }
+    sc *= (g.gmul ? g.gmul[0] : 1.f);
+    store_dl(dl0, va, vb, sc);
+    __syncthreads();
+    WSTAMP(1);
+
+    f32x16 acc[DWN ? RT : 1];
+    if constexpr (DWN) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+    }
+
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        const float* cur = ((t - t0) & 1) ? dl1 : dl0;
+        float* nxt = ((t - t0) & 1) ? dl0 : dl1;
+        const int tn = min(t + 1, t1 - 1);
+        float fvl[DWN ? 32 : 1];
+        if constexpr (DWN) turn(raw, fvl);
+        if (t - t0 < 4) WSTAMP(2 + 4 * (t - t0));
+        load_dl(tn, va, vb);
+        if constexpr (DWN) load_raw(tn, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t - t0 < 4) WSTAMP(3 + 4 * (t - t0));
+#ifdef DENET_DIAG_BW_NOMFMA
+        if (have && g.P < 0) {
+#else
+        if (have) {
+#endif
+            if constexpr (DWN) {
+                // A = dL rows from LDS, 16 positions (4 x 16 bytes) per group, the next group requested
+                // before the MFMAs of the current one
+                f32x4 A[2][4];
+                auto lda = [&](int gi, f32x4 (&d)[4]) {
+                    const float* r = cur + (32 * (gi >> 1) + j) * CLW_LD + 32 * hh + 16 * (gi & 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(r + 4 * q);
+                };
+                lda(0, A[0]);
+#pragma unroll
+                for (int gi = 0; gi < RT * 2; ++gi) {
+                    if (gi + 1 < RT * 2) lda(gi + 1, A[(gi + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[gi >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                A[gi & 1][q][e], fvl[16 * (gi & 1) + 4 * q + e], acc[gi >> 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                const int p0 = t * CL_TP, pa = p0 + 2 * j;
+                f32x16 a0, a1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+                // B = dL rows from LDS, 8 rows (4 x 8 bytes per lane) per group, the next group requested
+                // before the MFMAs of the current one; groups past K are skipped (uniform)
+                f32x2 Bf[2][4];
+                auto ldb = [&](int gi, f32x2 (&d)[4]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        d[q] = *reinterpret_cast<const f32x2*>(cur + (8 * gi + 2 * q + hh) * CLW_LD + 2 * j);
+                };
+                ldb(0, Bf[0]);
+#pragma unroll
+                for (int gi = 0; gi < RT * 4; ++gi) {
+                    if (gi + 1 < RT * 4) ldb(gi + 1, Bf[(gi + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (8 * gi < K) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][0], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][1], a1, 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    T* dst = dFq + ((int64_t)n * C + c) * P + pa;
+#ifdef DENET_DIAG_BW_NOSTORE
+                    if (a0[e] != 12345.f) continue;
+#endif
+                    if (pa + 1 < P) {
+                        if constexpr (sizeof(T) == 4) {
+                            *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{a0[e], a1[e]};
+                        } else {
+                            *reinterpret_cast<u16x2_u*>(dst) = u16x2_u{f32_to_bf16(a0[e]), f32_to_bf16(a1[e])};
+                        }
+                    } else if (pa < P) {
+                        FeatIO<T>::store(dst, a0[e]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t - t0 < 4) WSTAMP(4 + 4 * (t - t0));
+        store_dl(nxt, va, vb, sc);
+        __syncthreads();
+        if (t - t0 < 4) WSTAMP(5 + 4 * (t - t0));
+    }
+    WSTAMP(30);
+
+    if constexpr (DWN) {
+        if (have) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (kr < K) dWn_part[(((int64_t)n * ngrp + grp) * K + kr) * C + ct * 32 + j] = acc[rt][e];
+                }
+        }
+    }
+    WSTAMP(31);
+}
+
+// groups of position tiles per episode for the persistent kernel: one round of blocks over the chip
+// (2 roles x N x groups <= ~256 CUs) once there is more work than that, otherwise one tile per block
+__host__ __forceinline__ int cls_bwd_wide_groups(int64_t N, int64_t P) {
+    const int64_t ntile = (P + CL_TP - 1) / CL_TP;
+    const int64_t tpb = (2 * N * ntile + 255) / 256;
+    return (int)((ntile + tpb - 1) / tpb);
+}
+
 template <typename T, int RT>
 __global__ __launch_bounds__(256) void classify_bwd_kernel(ClsBwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // dL [KP][CL_LD]

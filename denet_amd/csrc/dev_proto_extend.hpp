@@ -246,6 +246,7 @@ struct PeParamsArgs {
     float Pf;
     float *dW1, *db1, *dW2, *db2, *dWl, *dbl, *dweight;
     const float* dh_part = nullptr;
+    DropGen wdrop = {0u, 0u, 0u, 1.f, 0};   // used where weight_mask is null (train-mode entry points)
 };
 // blocks per role: roles 0..2 need C/WG_ROWS blocks, role 3 needs K * C/16
 __host__ __device__ __forceinline__ int pe_params_gx(int K, int C) {
@@ -297,6 +298,9 @@ __device__ __forceinline__ void proto_extend_bwd_params_body(const PeParamsArgs&
             for (int jj = 0; jj < way; ++jj) novel = novel || (labels[(int64_t)n * way + jj] == k);
             if (weight_mask) {
                 const f32x4 m = *reinterpret_cast<const f32x4*>(weight_mask + ((int64_t)n * K + k) * C + col);
+                v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
+            } else if (a.wdrop.on) {
+                const f32x4 m = drop_mult4(a.wdrop, DENET_DROP_WEIGHT, (unsigned)((((int64_t)n * K + k) * C + col) >> 2));
                 v[0] *= m[0]; v[1] *= m[1]; v[2] *= m[2]; v[3] *= m[3];
             }
             const float keep = novel ? 0.f : 1.f;

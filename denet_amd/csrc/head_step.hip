@@ -75,6 +75,24 @@ __global__ __launch_bounds__(64 * B1_NW) void head_bwd_dwn_kernel(ClsBwdArgs g, 
     }
 }
 
+// K > 32: persistent blocks (dev_classify.hpp, classify_bwd_wide_body); g.n_part = groups per episode
+template <typename T, int RT>
+__global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsBwdArgs g, ClsBwdArgs g2,
+                                                                            const float* __restrict__ part_p, int NB,
+                                                                            int parts_p, float* __restrict__ losses) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ngrp = g.n_part;
+    if ((int)blockIdx.x < ngrp) {
+        classify_bwd_wide_body<T, RT, true>(g, blockIdx.y, blockIdx.x, sm);
+        if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+            __syncthreads();
+            loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
+        }
+    } else {
+        classify_bwd_wide_body<T, RT, false>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+    }
+}
+
 template <int CJ, int NS>
 __global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a, PeParamsArgs pa, int nchain) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -101,6 +119,14 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, hipStream_t st) {
+    if constexpr (RT >= 2) {
+        const size_t ldw = CLW_BWD_LDS(RT);
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT>), ldw))
+            return DENET_E_LAUNCH;
+        hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                           dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+        return DENET_OK;
+    }
     const size_t lds = CLS_BWD_LDS_NW(g.K, B1_NW);
     if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_kernel<T, RT>), lds)) return DENET_E_LAUNCH;
     hipLaunchKernelGGL((head_bwd_dwn_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N), dim3(64 * B1_NW), lds,
@@ -152,7 +178,7 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
 int denet_classify_build_fwd(const void* Fq, int feat_dtype, const float* weight, const float* weight_mask,
                              const float* proto_part, const float* bl, const int64_t* labels, int64_t N, int64_t way,
                              int64_t K, int64_t C, int64_t P, float* Wn_out, float* logits, float* logits_binary,
-                             void* stream);
+                             const DropGen* wdrop, void* stream);
 
 #define RT_DISPATCH(fn, T, RT, ...)                                \
     ((RT) == 1 ? fn<T, 1>(__VA_ARGS__) : (RT) == 2 ? fn<T, 2>(__VA_ARGS__) \
@@ -185,11 +211,23 @@ extern "C" int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t sho
             return DENET_E_LAUNCH;                                                                     \
     } while (0)
 
-extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
+// Dropout generators of a train-mode call: off for a null `drop`; p outside [0, 1) is rejected.
+static int dropgens(const denet_dropout_t* drop, DropGen& gd, DropGen& wd) {
+    gd = wd = DropGen{0u, 0u, 0u, 1.f, 0};
+    if (!drop) return DENET_OK;
+    if (!(drop->p_gate >= 0.f && drop->p_gate < 1.f) || !(drop->p_weight >= 0.f && drop->p_weight < 1.f))
+        return DENET_E_BADARG;
+    gd = make_dropgen(drop->seed, drop->p_gate);
+    wd = make_dropgen(drop->seed, drop->p_weight);
+    return DENET_OK;
+}
+
+extern "C" int denet_head_step_train_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
                                    const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
                                    const float* wgt, const float* weight, const float* W1, const float* b1,
                                    const float* W2, const float* b2, const float* Wl, const float* bl,
-                                   const float* gate_mask, const float* weight_mask, int64_t N, int64_t way,
+                                   const float* gate_mask, const float* weight_mask,
+                                   const denet_dropout_t* drop, int64_t N, int64_t way,
                                    int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
                                    int with_grad, float* logits_full, float* logits_binary,
                                    float* losses /*[2]: loss_k, loss_p*/, void* ws, int64_t ws_bytes,
@@ -205,17 +243,19 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
     const int64_t pk_run = with_grad ? pk : denet_upsample_loss_parts(K, h, w, H, W, 0);
     if (!(C == 64 || C == 256) || K > 128 || shot > 8) return DENET_E_UNSUPPORTED;
     if (!Fq || !Fs || !Ys || !labels || !weight || !W1 || !b1 || !W2 || !b2 || !Wl || !bl) return DENET_E_BADARG;
+    DropGen gd, wd;
+    TRY(dropgens(drop, gd, wd));
     PROBED(DENET_K_MASKED_SUM_FWD,
            denet_masked_pool_fwd_chain(Fs, feat_dtype, Ys, B, C, H, W, h, w, s.mask, s.cnt, s.S, W1, s.pre1_part,
                                        stream));
     {
         GateProjArgs ga{s.pre1_part, s.S, s.cnt, b1, W2, b2, Wl, gate_mask, (int)shot, s.hidden, s.gate, s.pool,
-                        s.proto_part};
+                        s.proto_part, gd};
         PROBED(DENET_K_PROTO_EXTEND_FWD, launch_gate_proj(ga, (int)NB, (int)C, (int)shot, (hipStream_t)stream));
     }
     PROBED(DENET_K_CLASSIFY_FWD,
            denet_classify_build_fwd(Fq, feat_dtype, weight, weight_mask, s.proto_part, bl, labels, N, way, K, C, P,
-                                    s.Wn, logits_full, logits_binary, stream));
+                                    s.Wn, logits_full, logits_binary, &wd, stream));
     if (Yq_full && Yq) {
         PROBED(DENET_K_WCE_FWD,
                denet_loss_pair_fwd(logits_full, Yq_full, wgt, logits_binary, Yq, N, NB, K, h, w, H, W, 0.25f, 2.f,
@@ -236,9 +276,24 @@ extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtyp
     return DENET_OK;
 }
 
-extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels, const float* W1,
+extern "C" int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
+                                   const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
+                                   const float* wgt, const float* weight, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, const float* Wl, const float* bl,
+                                   const float* gate_mask, const float* weight_mask, int64_t N, int64_t way,
+                                   int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w, int64_t H, int64_t W,
+                                   int with_grad, float* logits_full, float* logits_binary,
+                                   float* losses /*[2]: loss_k, loss_p*/, void* ws, int64_t ws_bytes,
+                                   const denet_probe_t* probe, void* stream) {
+    return denet_head_step_train_fwd(Fq, Fs, feat_dtype, Ys, labels, Yq, Yq_full, wgt, weight, W1, b1, W2, b2, Wl, bl,
+                                     gate_mask, weight_mask, nullptr, N, way, shot, K, C, h, w, H, W, with_grad,
+                                     logits_full, logits_binary, losses, ws, ws_bytes, probe, stream);
+}
+
+extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const int64_t* labels, const float* W1,
                                    const float* W2, const float* Wl, const float* gate_mask,
-                                   const float* weight_mask, const float* grad_loss_k /*device scalar or NULL*/,
+                                   const float* weight_mask, const denet_dropout_t* drop,
+                                   const float* grad_loss_k /*device scalar or NULL*/,
                                    int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                                    int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
                                    float* db2, float* dWl, float* dbl, float* losses /*NULL unless deferred*/,
@@ -259,10 +314,13 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
     if (ws_bytes < s.total) return DENET_E_WORKSPACE;
     const int64_t B = N * way * shot, P = h * w, NB = N * way;
     if (P * 4 > 64 * 1024 || B * ((C + 15) / 16) > (int64_t)1 << 30) return DENET_E_UNSUPPORTED;
-    const int n_part = (int)denet_classify_bwd_parts(P);
     const int RT = (int)((K + 31) / 32);
+    // dWn slabs per episode: one per position tile, or (K > 32, persistent blocks) one per tile group
+    const int n_part = RT >= 2 ? cls_bwd_wide_groups(N, P) : (int)denet_classify_bwd_parts(P);
     const bool f32 = feat_dtype == DENET_F32;
     hipStream_t st = (hipStream_t)stream;
+    DropGen gd, wd;
+    TRY(dropgens(drop, gd, wd));
 
     ClsBwdArgs g{Fq, s.Wn, s.dlog_a, s.dlog_b, nullptr, grad_loss_k, s.part_k, (int)pk, (int)N, (int)K, (int)C,
                  (int)P, n_part, nullptr, s.dWn_part, s.scale};
@@ -284,11 +342,11 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
     PeParamsArgs pa{nullptr, s.u2, s.u3, s.S, s.hidden, s.pool, s.dWn_part, weight_mask, labels, n_part, (int)N, (int)way,
-                    (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part};
+                    (int)B, (int)K, (int)C, (float)P, dW1, db1, dW2, db2, dWl, dbl, dweight, s.dh_part, wd};
     // B2: sliced chain, middle || dweight
     if (!only_dfs) {
         ChainMidArgs cm{s.dWn_part, s.S, s.cnt, s.gate, gate_mask, Wl, W2, labels, n_part, (int)way, (int)shot,
-                        (int)K, s.u2, s.u3, s.dpool, s.dh_part};
+                        (int)K, s.u2, s.u3, s.dpool, s.dh_part, gd};
         const bool on = probe && probe->which == DENET_K_PE_BWD_CHAIN && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
         int rc = launch_bwd_mid(cm, pa, (int)NB, (int)C, (int)shot, st);
@@ -321,5 +379,41 @@ extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
+    return DENET_OK;
+}
+
+extern "C" int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels, const float* W1,
+                                   const float* W2, const float* Wl, const float* gate_mask,
+                                   const float* weight_mask, const float* grad_loss_k /*device scalar or NULL*/,
+                                   int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                                   int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
+                                   float* db2, float* dWl, float* dbl, float* losses /*NULL unless deferred*/,
+                                   int flags, void* ws, int64_t ws_bytes, const denet_probe_t* probe,
+                                   void* stream) {
+    return denet_head_step_train_bwd(Fq, feat_dtype, labels, W1, W2, Wl, gate_mask, weight_mask, nullptr, grad_loss_k,
+                                     N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl,
+                                     losses, flags, ws, ws_bytes, probe, stream);
+}
+
+// The multipliers the train-mode step generates for (seed, stream_id, p), as a tensor: out[i], i < n.
+// stream_id DENET_DROPOUT_GATE: element (b, c) of the gate pre-activation [B][C]; DENET_DROPOUT_WEIGHT:
+// element (n, k, c) of the per-episode class weights [N][K][C].
+__global__ void __launch_bounds__(256) dropout_mask_kernel(DropGen g, unsigned stream_id, int64_t n, float* out) {
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= n) return;
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (g.on) m = drop_mult4(g, stream_id, (unsigned)i4);
+    for (int t = 0; t < 4; ++t)
+        if (i4 * 4 + t < n) out[i4 * 4 + t] = m[t];
+}
+
+extern "C" int denet_dropout_mask(uint64_t seed, int stream_id, float p, int64_t n, float* out, void* stream) {
+    if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) return DENET_E_BADARG;
+    if (stream_id != DENET_DROPOUT_GATE && stream_id != DENET_DROPOUT_WEIGHT) return DENET_E_BADARG;
+    if (n > ((int64_t)1 << 34)) return DENET_E_UNSUPPORTED;          // 32-bit counter of 4-element groups
+    const int64_t groups = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       make_dropgen(seed, p), (unsigned)stream_id, n, out);
+    DENET_CHECK_LAUNCH();
     return DENET_OK;
 }

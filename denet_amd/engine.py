@@ -62,31 +62,33 @@ class HeadStepEngine:
 
     # ---- bound step: the same buffers every iteration (training loops over resident batches, bench) ----
     def bind_step(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
-                  grad_loss_k=None):
+                  grad_loss_k=None, drop=None):
         """Fix the step's arguments (with_grad, deferred losses): run_forward() / run_backward(phase)
         then only make the library calls -- the argument conversion is done once here.  The tensors must
-        stay alive and in place."""
-        self._bound_args = (Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k)
+        stay alive and in place.  drop: a _lib.Dropout (train mode, masks generated in the kernels); the
+        library reads it at every call, so advance `drop.seed` in place between steps."""
+        self._bound_args = (Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k, drop)
         self._rebind()
 
     def _rebind(self):
         if self._bound_args is None:
             return
-        Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k = self._bound_args
+        Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k, drop = self._bound_args
         N, way, shot, K, C, h, w, H, W = self.dims
         P = [params[k] for k in PARAM_ORDER]
         deferred = Yq_full is not None
         have_focal = Yq is not None
         g = self.grads
-        fwd = _lib.bind("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask,
-                        weight_mask, N, way, shot, K, C, h, w, H, W,
+        fwd = _lib.bind("denet_head_step_train_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P,
+                        gate_mask, weight_mask, drop, N, way, shot, K, C, h, w, H, W,
                         _lib.GRAD_DEFER_LOSSES if deferred else 1, self.logits_full, self.logits_binary,
                         self.losses, self.ws, self.ws_bytes, self._probe)
         bwd = {}
         for phase, fl in ((0, 0), (1, _lib.BWD_NO_DFS), (2, _lib.BWD_ONLY_DFS)):
             bwd[phase] = _lib.bind(
-                "denet_head_step_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels, params["gam.gate.0.weight"],
-                params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
+                "denet_head_step_train_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels,
+                params["gam.gate.0.weight"], params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask,
+                weight_mask, drop, grad_loss_k,
                 N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
                 g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
                 g["map.linear.bias"], self.losses if deferred else None,
@@ -101,27 +103,27 @@ class HeadStepEngine:
         self._bound[1][phase](torch.cuda.current_stream().cuda_stream if stream is None else stream)
 
     def forward(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
-                with_grad=True, defer_losses=False):
-        """defer_losses: the loss scalars are reduced inside the first backward launch instead of a
+                with_grad=True, defer_losses=False, drop=None):
+        """drop: a _lib.Dropout for train mode (pass the same one to backward()).  defer_losses: the loss scalars are reduced inside the first backward launch instead of a
         launch of their own (self.losses is then valid after backward(); needs with_grad and Yq_full)."""
         N, way, shot, K, C, h, w, H, W = self.dims
         P = [params[k] for k in PARAM_ORDER]
         self._deferred = bool(defer_losses and with_grad and Yq_full is not None)
         self._have_focal = Yq is not None
         mode = _lib.GRAD_DEFER_LOSSES if self._deferred else (1 if with_grad else 0)
-        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask, weight_mask,
-             N, way, shot, K, C, h, w, H, W, mode, self.logits_full, self.logits_binary,
+        call("denet_head_step_train_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *P, gate_mask,
+             weight_mask, drop, N, way, shot, K, C, h, w, H, W, mode, self.logits_full, self.logits_binary,
              self.losses, self.ws, self.ws_bytes, self._probe)
 
-    def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None, phase=0):
+    def backward(self, Fq, labels, params, gate_mask=None, weight_mask=None, grad_loss_k=None, phase=0, drop=None):
         """phase 0: the whole backward.  phase 1: every gradient except dFs (the parameter-gradient
         bucket is complete afterwards); phase 2: dFs.  Data-parallel callers start the bucket's
         all-reduce between phases 1 and 2 so that it overlaps with the dFs stream."""
         N, way, shot, K, C, h, w, H, W = self.dims
         g = self.grads
         flags = (_lib.BWD_HAVE_FOCAL if self._have_focal else 0) | {0: 0, 1: _lib.BWD_NO_DFS, 2: _lib.BWD_ONLY_DFS}[phase]
-        call("denet_head_step_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels, params["gam.gate.0.weight"],
-             params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, grad_loss_k,
+        call("denet_head_step_train_bwd", Fq, feat_code(Fq, self.dFq, self.dFs), labels, params["gam.gate.0.weight"],
+             params["gam.gate.2.weight"], params["map.linear.weight"], gate_mask, weight_mask, drop, grad_loss_k,
              N, way, shot, K, C, h, w, H, W, self.dFq, self.dFs, g["weight"], g["gam.gate.0.weight"],
              g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
              g["map.linear.bias"], self.losses if self._deferred else None, flags,

@@ -14,9 +14,13 @@ What differs, on purpose:
   * class labels are read on the device: no ``label.item()`` sync per way
     (model/common.py:328), except in ``support_free`` mode, whose ``record``
     dictionary lives on the host in the reference too;
-  * dropout masks (gate: model/common.py:231, class weights: :326) are drawn
-    with ``torch.bernoulli`` on the device, one tensor per batch instead of one
-    draw per episode: same distribution, different random stream;
+  * dropout masks (gate: model/common.py:231, class weights: :326) come from the
+    library's counter-based generator (Philox4x32-10, include/denet_hip.h
+    "T1 in train mode"), keyed by ONE 64-bit seed per forward that is drawn from
+    torch's CPU generator (so ``torch.manual_seed`` still fixes the run): same
+    distribution as ``nn.Dropout``, different random stream.  The fused step
+    (``HeadStepEngine`` / ``HeadStepFunction`` with ``drop=``) generates the same
+    multipliers inside its kernels from the same seed;
   * the binary logits are not differentiable (the reference only ever calls
     ``loss_k.backward()``: trainer/trainers.py:972-974).
 """
@@ -110,20 +114,33 @@ class WeightEstimator(nn.Module):
         g0, g2, lin = self.gam.gate[0], self.gam.gate[2], self.map.linear
         return (self.weight, g0.weight, g0.bias, g2.weight, g2.bias, lin.weight, lin.bias)
 
-    def _dropout_masks(self, B, N, device):
-        """Already-scaled multipliers (0 or 1/(1-p)), or None in eval mode."""
+    def dropout_config(self, seed=None):
+        """(seed, p_gate, p_weight) of the next train-mode forward -- what the fused step takes as
+        ``drop`` -- or None in eval mode.  The seed comes from torch's CPU generator (no device sync)."""
         if not self.training:
-            return None, None
+            return None
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        return seed, float(self.gam.gate[3].p), float(self.dropout.p)
 
-        def draw(shape, p):
+    def _dropout_masks(self, B, N, device, seed=None):
+        """Already-scaled multipliers (0 or 1/(1-p)) as tensors, or None in eval mode: the values the
+        fused step would generate in its kernels for the same seed (denet_dropout_mask)."""
+        cfg = self.dropout_config(seed)
+        if cfg is None:
+            return None, None
+        seed, pg, pw = cfg
+        self.last_dropout_seed = seed
+
+        def draw(stream, shape, p):
             if p <= 0.0:
                 return None
             if p >= 1.0:
                 return torch.zeros(shape, device=device)
-            keep = torch.full(shape, 1.0 - p, device=device)
-            return torch.bernoulli(keep) / (1.0 - p)
+            return ops.dropout_mask(seed, stream, p, shape, device)
 
-        return draw((B, self.depth), self.gam.gate[3].p), draw((N, self.num_classes, self.depth), self.dropout.p)
+        return (draw(ops.DROPOUT_GATE, (B, self.depth), pg),
+                draw(ops.DROPOUT_WEIGHT, (N, self.num_classes, self.depth), pw))
 
     @staticmethod
     def _labels2d(labels, N):

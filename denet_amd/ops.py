@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import call, feat_code, query
 
 IGNORE_INDEX = 255
+DROPOUT_GATE, DROPOUT_WEIGHT = _lib.DROPOUT_GATE, _lib.DROPOUT_WEIGHT
 
 
 def _f32(*shape, device):
@@ -438,10 +439,14 @@ class HeadStepFunction(torch.autograd.Function):
     (loss_k, loss_p, logits_full, logits_binary); only loss_k is differentiable."""
 
     @staticmethod
-    def forward(ctx, Fq, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask):
+    def forward(ctx, Fq, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask,
+                drop=None):
+        """drop: (seed, p_gate, p_weight) -- train-mode dropout generated in the kernels; the backward
+        regenerates the same multipliers from it."""
         N, way, shot, C, h, w = Fs.shape
         K = weight.shape[0]
         dev = Fq.device
+        ctx.drop = _lib.Dropout(*drop) if drop is not None else None
         Fq, Fs = Fq.contiguous(), Fs.contiguous()
         params = tuple(t.contiguous() for t in (weight, W1, b1, W2, b2, Wl, bl))
         labels = _as_i64(labels).contiguous()
@@ -457,8 +462,8 @@ class HeadStepFunction(torch.autograd.Function):
         logits = _f32(N, K, h, w, device=dev)
         binl = _f32(N * way, 2, h, w, device=dev)
         losses = torch.zeros(2, dtype=torch.float32, device=dev)
-        call("denet_head_step_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *params,
-             gate_mask, weight_mask, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
+        call("denet_head_step_train_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *params,
+             gate_mask, weight_mask, ctx.drop, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
              ws, nbytes, None)
         ctx.dims = (N, way, shot, K, C, h, w, H, W)
         ctx.have_focal = Yq is not None
@@ -475,7 +480,7 @@ class HeadStepFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_k, g_p, g_l, g_b):
         if g_k is None:
-            return (None,) * 16
+            return (None,) * 17
         N, way, shot, K, C, h, w, H, W = ctx.dims
         sv = list(ctx.saved_tensors)
         Fq, labels, W1, W2, Wl = sv[:5]
@@ -489,7 +494,16 @@ class HeadStepFunction(torch.autograd.Function):
         dW1, dW2, dWl = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wl)
         db1, db2, dbl = _f32(C, device=dev), _f32(C, device=dev), _f32(C, device=dev)
         g = g_k.contiguous().float().reshape(1)
-        call("denet_head_step_bwd", Fq, feat_code(Fq, dFq, dFs), labels, W1, W2, Wl, gate_mask, weight_mask, g,
+        call("denet_head_step_train_bwd", Fq, feat_code(Fq, dFq, dFs), labels, W1, W2, Wl, gate_mask, weight_mask,
+             ctx.drop, g,
              N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, None,
              1 if ctx.have_focal else 0, ctx.ws, ctx.ws.numel(), None)
-        return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 7
+        return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 8
+
+
+def dropout_mask(seed, stream_id, p, shape, device):
+    """The multipliers the train-mode step generates for (seed, stream id, p), as a tensor
+    (denet_dropout_mask): feeds the stand-alone ops' mask pointers with the same dropout."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    call("denet_dropout_mask", seed, stream_id, p, out.numel(), out)
+    return out

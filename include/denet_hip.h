@@ -292,6 +292,47 @@ int denet_head_step_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
                         int flags /* DENET_BWD_* */, void* ws, int64_t ws_bytes,
                         const denet_probe_t* probe, void* stream);
 
+/* ---- T1 in train mode: dropout generated inside the kernels --------------------
+ * WeightEstimator in train() mode (model/common.py:231 `nn.Dropout` of the gate, :326
+ * `self.dropout(self.weight)` per episode; the trainer calls model.train() at
+ * trainer/trainers.py:938).  The reference draws the masks from torch's generator; here the
+ * multipliers (0 with probability p, else 1/(1-p)) are a pure function of (seed, stream id,
+ * element index): Philox4x32-10, key = seed, counter = (index / 4, stream id, 0, 0), drop iff
+ * the 32-bit output < round(p * 2^32).  The forward applies them in F2 (gate) and while F3
+ * assembles Wn; the backward regenerates them from the same `drop`, so nothing but the seed is
+ * kept between the calls.  The caller advances `seed` every step.  A non-NULL mask pointer wins
+ * over the generator (injected masks: parity tests); `drop` NULL and both pointers NULL = eval
+ * mode (= denet_head_step_fwd / _bwd, which are these calls with drop = NULL).
+ * p in [0, 1); p = 0 leaves that site without dropout.
+ * denet_dropout_mask writes the multipliers of one stream as a tensor (tests; callers of the
+ * stand-alone denet_proto_extend_fwd / _bwd who want the same masks as pointers). */
+#define DENET_DROPOUT_GATE    1   /* element (b, c) of the gate pre-activation, [N*way*shot][C] */
+#define DENET_DROPOUT_WEIGHT  2   /* element (n, k, c) of the episode's class weights, [N][K][C] */
+typedef struct denet_dropout {
+    uint64_t seed;
+    float p_gate;       /* model/common.py:231, 0.5 in the reference */
+    float p_weight;     /* model/common.py:274 drop_rate, 0.5 in the reference */
+} denet_dropout_t;
+int denet_dropout_mask(uint64_t seed, int stream_id, float p, int64_t n, float* out, void* stream);
+int denet_head_step_train_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
+                        const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
+                        const float* wgt, const float* weight, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const float* Wl, const float* bl,
+                        const float* gate_mask, const float* weight_mask,
+                        const denet_dropout_t* drop /* HOST pointer, read during the call */,
+                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
+                        int64_t h, int64_t w, int64_t H, int64_t W, int with_grad,
+                        float* logits_full, float* logits_binary, float* losses,
+                        void* ws, int64_t ws_bytes, const denet_probe_t* probe, void* stream);
+int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const int64_t* labels,
+                        const float* W1, const float* W2, const float* Wl,
+                        const float* gate_mask, const float* weight_mask,
+                        const denet_dropout_t* drop /* the forward's */, const float* grad_loss_k,
+                        int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                        int64_t H, int64_t W, void* dFq, void* dFs, float* dweight, float* dW1, float* db1, float* dW2,
+                        float* db2, float* dWl, float* dbl, float* losses, int flags,
+                        void* ws, int64_t ws_bytes, const denet_probe_t* probe, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,3 +282,36 @@ def min_top2_margin(up: torch.Tensor) -> float:
     """Smallest top-1/top-2 gap over all pixels (SURVEY.md §7 hard parts)."""
     top = up.topk(2, dim=1)[0]
     return float((top[:, 0] - top[:, 1]).min())
+
+
+# ---- train-mode dropout (nn.Dropout at model/common.py:231 and :274/:326) ----------------------------
+# The reference draws its masks from torch's generator, so no implementation can reproduce its stream;
+# what it fixes is the distribution: multiplier 0 with probability p, 1/(1-p) otherwise.  The library's
+# stream is Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11; Random123), restated here and pinned by
+# Random123's published known-answer vectors (tests/test_oracle_golden.py).
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Counter (c0..c3) and key (k0, k1) as uint32 arrays / ints -> four uint32 arrays (as uint64)."""
+    c0, c1, c2, c3 = [np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3)]
+    k0, k1, m32, s32 = np.uint64(k0), np.uint64(k1), np.uint64(0xFFFFFFFF), np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> s32) ^ c1 ^ k0) & m32, p1 & m32, ((p0 >> s32) ^ c3 ^ k1) & m32, p0 & m32
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0, c1, c2, c3
+
+
+def dropout_mask(seed: int, stream_id: int, p: float, n: int) -> np.ndarray:
+    """include/denet_hip.h `denet_dropout_mask`: key = seed, counter = (i // 4, stream_id, 0, 0), element i takes
+    output word i % 4; dropped iff word < round(p * 2^32); kept elements carry float32(1 / (1 - p))."""
+    if not 0.0 < p < 1.0:
+        return np.ones(n, dtype=np.float32)
+    groups = (n + 3) // 4
+    idx = np.arange(groups, dtype=np.uint64)
+    zero = np.zeros(groups, dtype=np.uint64)
+    r = np.stack(philox4x32_10(idx, zero + np.uint64(stream_id), zero, zero, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF),
+                 axis=1).reshape(-1)[:n]
+    thresh = min(int(float(np.float32(p)) * 4294967296.0 + 0.5), 4294967295)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return np.where(r < np.uint64(thresh), np.float32(0.0), scale).astype(np.float32)

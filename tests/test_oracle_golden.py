@@ -110,3 +110,22 @@ def test_trainer_glue_fixture(golden_dir):
             bi.update(Yq[:, i], fused[:, i].max(1)[1].numpy(), cls[:, i])
     assert list(bi.inter.keys()) == z["out:nway_keys"].tolist()
     assert bi.mean_iou() == float(z["out:nway_mean"]) and bi.mean_bf_iou() == float(z["out:nway_bf"])
+
+
+def test_philox_known_answers_and_dropout_distribution():
+    """Random123's published known-answer vectors for philox4x32-10 (kat_vectors: counter, key -> output) pin the
+    generator the library's train-mode dropout uses; the multipliers are Bernoulli(1-p) / (1-p)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x) for x in O.philox4x32_10(*ctr, *key))
+        assert got == want
+    m = O.dropout_mask(99, 1, 0.5, 1 << 20)
+    assert set(np.unique(m).tolist()) == {0.0, 2.0}
+    assert abs(float((m != 0).mean()) - 0.5) < 0.01
+    # element i depends only on (seed, stream, i): a shorter request is a prefix
+    assert np.array_equal(O.dropout_mask(99, 1, 0.5, 1001), m[:1001])
+    assert not np.array_equal(O.dropout_mask(99, 2, 0.5, 1001), m[:1001])
+    assert np.array_equal(O.dropout_mask(99, 1, 0.0, 7), np.ones(7, np.float32))
