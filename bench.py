@@ -20,6 +20,7 @@ same batch, on this host's cores.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -243,21 +244,30 @@ def main():
         # at least 8 samples whatever --steps is (the driver runs 20 steps)
         every = max(1, min(args.probe_every, args.steps // 8))
         pairs = {i: (Event(), Event()) for i in range(0, args.steps, every)}
+    # no collector pause inside a timed loop: re-binding for the probes allocates closures, and a full collection
+    # of torch's object graph (measured 42 ms, once) would be charged to whichever step triggers it
+    gc.collect()
+    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_us = []
     for i in range(args.steps):
+        h0 = time.perf_counter()
         if pairs:
             if i in pairs:
                 eng.set_probe(probe, *pairs[i])
             elif (i - 1) in pairs:
                 eng.set_probe(None, None, None)
         runner()
+        host_us.append((time.perf_counter() - h0) * 1e6)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
+    dbg("host us per step: median %.1f, max %.1f, over 200 us: %s" % (
+        statistics.median(host_us), max(host_us), [(i, round(h)) for i, h in enumerate(host_us) if h > 200][:20]))
     eng.set_probe(None, None, None)
     dbg("timed region done")
     elapsed = t1 - t0
@@ -292,10 +302,12 @@ def main():
                       "dropout": "Philox4x32-10 in F2 / F3 / B2, p=0.5 gate and class weights, new seed per step",
                       "loss_k": float(eng.losses[0].item())}
         train_now[0] = False
+        gc.enable()
         eng.bind_step(*bind_args, drop=None)
         step()                                   # eng.losses back to the eval-mode values reported below
         torch.cuda.synchronize()
 
+    gc.enable()
     probe_us = None
     if pairs:
         probe_us = statistics.mean(a.elapsed_ms(b) * 1e3 for a, b in pairs.values())

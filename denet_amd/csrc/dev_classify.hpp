@@ -46,6 +46,14 @@ __device__ __forceinline__ float episode_den(const float* __restrict__ part_k, i
     return wave_sum(de);
 }
 
+// the calling lane's share of the episode's den partials (same order of additions as episode_den)
+__device__ __forceinline__ float part_k_lane(const float* __restrict__ part_k, int parts_k, int n) {
+    float de = 0.f;
+    const int lane = threadIdx.x & 63;
+    for (int y = lane; y < parts_k; y += 64) de += part_k[((int64_t)n * parts_k + y) * 2 + 1];
+    return de;
+}
+
 template <typename T, int RT, int NW>
 __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, int tile, float* sm) {
     const T* __restrict__ Fq = reinterpret_cast<const T*>(g.Fq);
@@ -282,15 +290,15 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
     T* __restrict__ dFq = reinterpret_cast<T*>(g.dFq);
     float* __restrict__ dWn_part = g.dWn_part;
     const int K = g.K, C = g.C, P = g.P, ngrp = g.n_part;
-    constexpr int NT = CLW_BWD_NW * 64, NL = RT * 4, NA = RT * 16;
+    constexpr int NT = CLW_BWD_NW * 64, NA = RT * 16;
     const int ntile = (P + CL_TP - 1) / CL_TP;
     const int t0 = (int)((int64_t)grp * ntile / ngrp), t1 = (int)((int64_t)(grp + 1) * ntile / ngrp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    const int KP = (K + 1) & ~1;
     const float* wn = g.Wn + (int64_t)n * K * C;
     const int ct = wave;
     const bool have = ct < (C >> 5);               // C = 64: waves 2.. only help with the staging
+    const int cc = min(ct, (C >> 5) - 1);
     const int r4 = lane >> 4, c16 = lane & 15;
     float* dl0 = sm;
     float* dl1 = sm + CLW_DL(RT);
@@ -299,91 +307,121 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
     for (int idx = K * CLW_LD + tid; idx < RT * 32 * CLW_LD; idx += NT) { dl0[idx] = 0.f; dl1[idx] = 0.f; }
 
     const bool have_b = dlog_b != nullptr;
-    const float* __restrict__ dlb = have_b ? dlog_b : dlog_a;
-    auto load_dl = [&](int tile, float (&va)[NL], float (&vb)[NL]) {
-#ifdef DENET_DIAG_BW_NODL
-        if (tile != t0) return;
-#endif
-        const int p0 = tile * CL_TP;
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const int idx = u * NT + tid;
-            const int k = idx >> 6, p = p0 + (idx & 63);
-            const bool ok = k < K && p < P;
-            const int64_t gi = ((int64_t)n * K + min(k, K - 1)) * P + min(p, P - 1);
-            const float xa = dlog_a[gi];
-            const float xb = dlb[gi];                  // no branch around a load: dlb = dlog_a when dlog_b is null
-            va[u] = ok ? xa : 0.f;
-            vb[u] = (ok && have_b) ? xb : 0.f;
-        }
+    const float* __restrict__ dlb = have_b ? dlog_b : dlog_a;      // no branch around a load
+    // dL staging: thread <-> RT quads (row k = idx >> 4, four positions 4 * (idx & 15)), idx = u * NT + tid
+    // Every quad load starts at min(p, P - 4): the partial last tile of an episode then needs no scalar path
+    // and no branch -- the lanes whose quad was moved back pick their elements (and zeros for the positions
+    // past P) when the tile goes to LDS: quad_fix(loaded, sh), sh = p - min(p, P - 4).
+    auto quad_fix = [&](const f32x4& l, int sh) {
+        f32x4 r;
+        r[0] = sh == 0 ? l[0] : sh == 1 ? l[1] : sh == 2 ? l[2] : sh == 3 ? l[3] : 0.f;
+        r[1] = sh == 0 ? l[1] : sh == 1 ? l[2] : sh == 2 ? l[3] : 0.f;
+        r[2] = sh == 0 ? l[2] : sh == 1 ? l[3] : 0.f;
+        r[3] = sh == 0 ? l[3] : 0.f;
+        return r;
     };
-    auto store_dl = [&](float* buf, const float (&va)[NL], const float (&vb)[NL], float sc) {
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const int idx = u * NT + tid;
-            if ((idx >> 6) < K) buf[(idx >> 6) * CLW_LD + (idx & 63)] = (va[u] + vb[u]) * sc;
-        }
+    // dL staging: thread <-> RT quads (row k = idx >> 4, four positions 4 * (idx & 15)), idx = u * NT + tid
+    auto load_dl_u = [&](int tile, int u, f32x4& xa, f32x4& xb) {
+        const int idx = u * NT + tid;
+        const int k = min(idx >> 4, K - 1), pq = min(tile * CL_TP + 4 * (idx & 15), P - 4);
+        const f32x4_u a = *reinterpret_cast<const f32x4_u*>(dlog_a + ((int64_t)n * K + k) * P + pq);
+        const f32x4_u b = *reinterpret_cast<const f32x4_u*>(dlb + ((int64_t)n * K + k) * P + pq);
+        xa = f32x4{a[0], a[1], a[2], a[3]};
+        xb = f32x4{b[0], b[1], b[2], b[3]};
     };
-    auto load_raw = [&](int tile, f32x4 (&raw)[8]) {
-        const int pb = tile * CL_TP + 4 * c16;
-        const bool fast = (tile + 1) * CL_TP <= P;
-        const int cc = min(ct, (C >> 5) - 1);
+    auto store_dl = [&](float* buf, int tile, const f32x4 (&va)[RT], const f32x4 (&vb)[RT], float sc) {
+        const bool part = (tile + 1) * CL_TP > P;          // uniform
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const T* rowp = Fq + ((int64_t)n * C + cc * 32 + 4 * i + r4) * P;
-            if (fast) {
-                if constexpr (sizeof(T) == 4) {
-                    const f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)rowp + pb);
-                    raw[i] = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    const u16x2_u v0 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb);
-                    const u16x2_u v1 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb + 2);
-                    raw[i] = f32x4{bf16_to_f32(v0[0]), bf16_to_f32(v0[1]), bf16_to_f32(v1[0]), bf16_to_f32(v1[1])};
-                }
-            } else {
+        for (int u = 0; u < RT; ++u) {
+            const int idx = u * NT + tid;
+            if ((idx >> 4) < K) {
+                const int pq = tile * CL_TP + 4 * (idx & 15);
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = FeatIO<T>::load(rowp + min(pb + e, P - 1));
-                    raw[i][e] = (pb + e < P) ? v : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = (va[u][e] + (have_b ? vb[u][e] : 0.f)) * sc;
+                if (part) v = quad_fix(v, pq - min(pq, P - 4));
+                *reinterpret_cast<f32x4*>(buf + (idx >> 4) * CLW_LD + 4 * (idx & 15)) = v;
             }
         }
     };
-    auto turn = [&](const f32x4 (&raw)[8], float (&dst)[32]) {
+    // Fq tile of this wave's 32 channels: load i = channels 4i .. 4i+3 (one per 16 lanes), 4 positions per lane
+    auto load_raw_i = [&](int tile, int i, f32x4& r) {
+        const int pb = min(tile * CL_TP + 4 * c16, P - 4);
+        const T* rowp = Fq + ((int64_t)n * C + cc * 32 + 4 * i + r4) * P;
+        if constexpr (sizeof(T) == 4) {
+            const f32x4_u v = *reinterpret_cast<const f32x4_u*>((const float*)rowp + pb);
+            r = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            const u16x2_u v0 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb);
+            const u16x2_u v1 = *reinterpret_cast<const u16x2_u*>((const unsigned short*)rowp + pb + 2);
+            r = f32x4{bf16_to_f32(v0[0]), bf16_to_f32(v0[1]), bf16_to_f32(v1[0]), bf16_to_f32(v1[1])};
+        }
+    };
+    auto turn = [&](int tile, const f32x4 (&raw)[8], float (&dst)[32]) {
+        const bool part = (tile + 1) * CL_TP > P;          // uniform
+        const int pb = tile * CL_TP + 4 * c16;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(tsm + (4 * i + r4) * CL_TS + 4 * c16) = raw[i];
+        for (int i = 0; i < 8; ++i) {
+            f32x4 v = raw[i];
+            if (part) v = quad_fix(v, pb - min(pb, P - 4));
+            *reinterpret_cast<f32x4*>(tsm + (4 * i + r4) * CL_TS + 4 * c16) = v;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(tsm + j * CL_TS + 32 * hh + 4 * m);
             dst[4 * m] = v[0]; dst[4 * m + 1] = v[1]; dst[4 * m + 2] = v[2]; dst[4 * m + 3] = v[3];
         }
     };
+    // one result row pair of a finished dFq tile: channel ct*32 + (e&3) + 8*(e>>2) + 4*hh, positions pa, pa+1
+    auto store_dfq_e = [&](int tile, int e, float x0, float x1) {
+        const int pa = tile * CL_TP + 2 * j;
+        const int c = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        T* dst = dFq + ((int64_t)n * C + c) * P + pa;
+#ifdef DENET_DIAG_BW_NOSTORE
+        if (x0 != 12345.f) return;
+#endif
+        if (pa + 1 < P) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{x0, x1};
+            } else {
+                *reinterpret_cast<u16x2_u*>(dst) = u16x2_u{f32_to_bf16(x0), f32_to_bf16(x1)};
+            }
+        } else if (pa < P) {
+            FeatIO<T>::store(dst, x0);
+        }
+    };
 
     // everything this block needs first is requested before the first wait
-    float va[NL], vb[NL];
+    f32x4 va[RT], vb[RT];
     f32x4 raw[8];
     float av[DWN ? 1 : NA];
     WSTAMP(0);
-    load_dl(t0, va, vb);
+    BSTAMP(0);
+    // the episode's loss denominator: its partials are requested first and reduced after the big loads are out
+    float de = 0.f;
+    if (g.part_k != nullptr) de = part_k_lane(g.part_k, g.parts_k, n);
+#pragma unroll
+    for (int u = 0; u < RT; ++u) load_dl_u(t0, u, va[u], vb[u]);
     if constexpr (DWN) {
-        load_raw(t0, raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) load_raw_i(t0, i, raw[i]);
     } else {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int kk = 2 * u + hh;
-            const float v = wn[(int64_t)min(kk, K - 1) * C + min(ct, (C >> 5) - 1) * 32 + j];
+            const float v = wn[(int64_t)min(kk, K - 1) * C + cc * 32 + j];
             av[u] = kk < K ? v : 0.f;
         }
     }
     float sc;
     if (g.part_k != nullptr) {
-        sc = 1.f / ((float)g.N * episode_den(g.part_k, g.parts_k, n));
+        sc = 1.f / ((float)g.N * wave_sum(de));
         if (g.scale_out != nullptr && grp == 0 && tid == 0) g.scale_out[n] = sc;
     } else {
         sc = g.scale ? g.scale[n] : 1.f;
     }
     sc *= (g.gmul ? g.gmul[0] : 1.f);
-    store_dl(dl0, va, vb, sc);
+    store_dl(dl0, t0, va, vb, sc);
     __syncthreads();
     WSTAMP(1);
 
@@ -394,95 +432,104 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
     }
+    // dFq: the finished tile waits in s0 / s1 and is stored between the MFMAs of the next tile
+    f32x16 s0, s1;
+    int ts = -1;                                    // tile held in s0 / s1 (-1: none)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
 
+    // The loads of tile t+1 and the stores of tile t-1 are ISSUED BETWEEN the MFMA groups of tile t, a few per
+    // group: a burst of them ahead of the MFMAs stalls the wave in the memory pipeline's issue queue (every CU
+    // asks for ~100 KB at once; measured 4 us per tile, scripts/diag/bwd_wide_stamps.hip) and the MFMAs of an
+    // in-order wave wait behind it.  The last iteration re-requests its own tile (no branch around loads).
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
         const float* cur = ((t - t0) & 1) ? dl1 : dl0;
         float* nxt = ((t - t0) & 1) ? dl0 : dl1;
         const int tn = min(t + 1, t1 - 1);
         float fvl[DWN ? 32 : 1];
-        if constexpr (DWN) turn(raw, fvl);
+        if constexpr (DWN) turn(t, raw, fvl);
         if (t - t0 < 4) WSTAMP(2 + 4 * (t - t0));
-        load_dl(tn, va, vb);
-        if constexpr (DWN) load_raw(tn, raw);
         __builtin_amdgcn_sched_barrier(0);
-        if (t - t0 < 4) WSTAMP(3 + 4 * (t - t0));
-#ifdef DENET_DIAG_BW_NOMFMA
-        if (have && g.P < 0) {
-#else
-        if (have) {
+        if constexpr (DWN) {
+            constexpr int NG = RT * 2;             // groups of 16 MFMAs
+            // A = dL rows from LDS, 16 positions (4 x 16 bytes) per group, requested one group ahead
+            f32x4 A[2][4];
+            auto lda = [&](int gi, f32x4 (&d)[4]) {
+                const float* r = cur + (32 * (gi >> 1) + j) * CLW_LD + 32 * hh + 16 * (gi & 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(r + 4 * q);
+            };
+            lda(0, A[0]);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) lda(gi + 1, A[(gi + 1) & 1]);
+#ifndef DENET_DIAG_BW_NODL
+                if (gi < RT) load_dl_u(tn, gi, va[gi], vb[gi]);
 #endif
-            if constexpr (DWN) {
-                // A = dL rows from LDS, 16 positions (4 x 16 bytes) per group, the next group requested
-                // before the MFMAs of the current one
-                f32x4 A[2][4];
-                auto lda = [&](int gi, f32x4 (&d)[4]) {
-                    const float* r = cur + (32 * (gi >> 1) + j) * CLW_LD + 32 * hh + 16 * (gi & 1);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(r + 4 * q);
-                };
-                lda(0, A[0]);
-#pragma unroll
-                for (int gi = 0; gi < RT * 2; ++gi) {
-                    if (gi + 1 < RT * 2) lda(gi + 1, A[(gi + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 8; ++i)
+                    if ((i * NG) / 8 == gi) load_raw_i(tn, i, raw[i]);
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef DENET_DIAG_BW_NOMFMA
+                if (have && g.P < 0) {
+#else
+                if (have) {
+#endif
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[gi >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                 A[gi & 1][q][e], fvl[16 * (gi & 1) + 4 * q + e], acc[gi >> 1], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
-                const int p0 = t * CL_TP, pa = p0 + 2 * j;
-                f32x16 a0, a1;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-                // B = dL rows from LDS, 8 rows (4 x 8 bytes per lane) per group, the next group requested
-                // before the MFMAs of the current one; groups past K are skipped (uniform)
-                f32x2 Bf[2][4];
-                auto ldb = [&](int gi, f32x2 (&d)[4]) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        d[q] = *reinterpret_cast<const f32x2*>(cur + (8 * gi + 2 * q + hh) * CLW_LD + 2 * j);
-                };
-                ldb(0, Bf[0]);
-#pragma unroll
-                for (int gi = 0; gi < RT * 4; ++gi) {
-                    if (gi + 1 < RT * 4) ldb(gi + 1, Bf[(gi + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (8 * gi < K) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][0], a0, 0, 0, 0);
-                            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][1], a1, 0, 0, 0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int c = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    T* dst = dFq + ((int64_t)n * C + c) * P + pa;
-#ifdef DENET_DIAG_BW_NOSTORE
-                    if (a0[e] != 12345.f) continue;
-#endif
-                    if (pa + 1 < P) {
-                        if constexpr (sizeof(T) == 4) {
-                            *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{a0[e], a1[e]};
-                        } else {
-                            *reinterpret_cast<u16x2_u*>(dst) = u16x2_u{f32_to_bf16(a0[e]), f32_to_bf16(a1[e])};
-                        }
-                    } else if (pa < P) {
-                        FeatIO<T>::store(dst, a0[e]);
-                    }
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            constexpr int NG = RT * 4;             // groups of 8 MFMAs (8 dL rows)
+            f32x16 a0, a1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+            // B = dL rows from LDS, 8 rows (4 x 8 bytes per lane) per group, requested one group ahead;
+            // groups past K are skipped (uniform)
+            f32x2 Bf[2][4];
+            auto ldb = [&](int gi, f32x2 (&d)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    d[q] = *reinterpret_cast<const f32x2*>(cur + (8 * gi + 2 * q + hh) * CLW_LD + 2 * j);
+            };
+            ldb(0, Bf[0]);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) ldb(gi + 1, Bf[(gi + 1) & 1]);
+#ifndef DENET_DIAG_BW_NODL
+                if ((gi & 1) == 0 && (gi >> 1) < RT) load_dl_u(tn, gi >> 1, va[gi >> 1], vb[gi >> 1]);
+#endif
+                if (have && ts >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if ((e * NG) / 16 == gi) store_dfq_e(ts, e, s0[e], s1[e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef DENET_DIAG_BW_NOMFMA
+                if (have && 8 * gi < K && g.P < 0) {
+#else
+                if (have && 8 * gi < K) {
+#endif
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][0], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][1], a1, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s0 = a0;
+            s1 = a1;
+            ts = t;
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (t - t0 < 4) WSTAMP(4 + 4 * (t - t0));
-        store_dl(nxt, va, vb, sc);
+        store_dl(nxt, tn, va, vb, sc);
         __syncthreads();
         if (t - t0 < 4) WSTAMP(5 + 4 * (t - t0));
     }
@@ -498,8 +545,14 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
                     if (kr < K) dWn_part[(((int64_t)n * ngrp + grp) * K + kr) * C + ct * 32 + j] = acc[rt][e];
                 }
         }
+    } else {
+        if (have && ts >= 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) store_dfq_e(ts, e, s0[e], s1[e]);
+        }
     }
     WSTAMP(31);
+    BSTAMP(1);
 }
 
 // groups of position tiles per episode for the persistent kernel: one round of blocks over the chip

@@ -41,7 +41,10 @@ class HeadStepEngine:
         for name, n, shp in zip(PARAM_ORDER, sizes, shapes):
             self.grads[name] = self.grad_bucket[off:off + n].view(shp)
             off += n
-        self._probe = None
+        # one probe record for the engine's lifetime: the library reads it at every call (host pointer), so
+        # switching the probe on / off or to another event pair is a field write, not a re-bind
+        self._probe = _lib.Probe()
+        self._probe.which = 0
         self._deferred = False
         self._have_focal = True
         self._bound = None
@@ -49,16 +52,16 @@ class HeadStepEngine:
 
     def set_probe(self, which, start_event, stop_event):
         """Bracket kernel `which` (a name in _lib.KERNEL_IDS, or None) with HIP events."""
+        p = self._probe
         if which is None:
-            self._probe = None
-            self._rebind()
+            p.which = 0
+            p.start = None
+            p.stop = None
             return
-        p = _lib.Probe()
-        p.which = _lib.KERNEL_IDS[which]
         p.start = start_event.h
         p.stop = stop_event.h
-        self._probe = p
-        self._rebind()
+        p.which = _lib.KERNEL_IDS[which]
+        self._probe_events = (start_event, stop_event)         # keep them alive while the record names them
 
     # ---- bound step: the same buffers every iteration (training loops over resident batches, bench) ----
     def bind_step(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,

@@ -1,6 +1,9 @@
 // Diagnostic: phase stamps of one block of the persistent K > 32 classifier backward (first backward launch of
 // the fused step), at C3 / C5 shapes, synthetic zeros.  Build twice: -DDENET_STAMP_ROLE_DWN=1 (dWn role) / =0 (dFq).
 #define DENET_STAMPS 1
+#define DENET_BLOCK_STAMPS 1
+#include <vector>
+#include <algorithm>
 #include "../../denet_amd/csrc/dev_classify.hpp"
 // the launch of head_step.hip without the loss reduction of block (0, 0)
 template <typename T, int RT>
@@ -25,6 +28,9 @@ int main(int argc, char** argv) {
     CK(hipMemset(da, 0, (size_t)N * K * P * 4)); CK(hipMemset(db, 0, (size_t)N * K * P * 4));
     unsigned long long* d_st; CK(hipMalloc(&d_st, 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    const int nblk = 2 * ngrp * N;
+    unsigned long long* d_bs; CK(hipMalloc(&d_bs, (size_t)nblk * 3 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &d_bs, sizeof(d_bs)));
     ClsBwdArgs g{Fq, Wn, da, db, nullptr, nullptr, nullptr, 0, N, K, C, P, ngrp, nullptr, slab, nullptr};
     ClsBwdArgs g2 = g; g2.dFq = dFq; g2.dWn_part = nullptr;
     const size_t lds = CLW_BWD_LDS(3);
@@ -45,6 +51,27 @@ int main(int argc, char** argv) {
             if (st[2 + 4 * t]) printf(" tile%d: turn@%llu issued@%llu mfma-done@%llu barrier@%llu |", t, (st[2 + 4 * t] - st[0]) * 10,
                                       (st[3 + 4 * t] - st[0]) * 10, (st[4 + 4 * t] - st[0]) * 10, (st[5 + 4 * t] - st[0]) * 10);
         printf(" loop end %llu, block end %llu\n", (st[30] - st[0]) * 10, (st[31] - st[0]) * 10);
+        std::vector<unsigned long long> bs((size_t)nblk * 3);
+        CK(hipMemcpy(bs.data(), d_bs, bs.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long s_min = ~0ull, s_max = 0, e_min = ~0ull, e_max = 0;
+        for (int b = 0; b < nblk; ++b) { s_min = std::min(s_min, bs[3 * b]); s_max = std::max(s_max, bs[3 * b]); e_min = std::min(e_min, bs[3 * b + 1]); e_max = std::max(e_max, bs[3 * b + 1]); }
+        std::vector<unsigned long long> dur[2];
+        for (int b = 0; b < nblk; ++b) dur[(b % (2 * ngrp)) >= ngrp].push_back(bs[3 * b + 1] - bs[3 * b]);
+        for (auto& d : dur) std::sort(d.begin(), d.end());
+        if (rep == 3) {
+            std::vector<std::pair<unsigned long long, int>> o;
+            for (int b = 0; b < nblk; ++b) o.push_back({bs[3 * b + 1] - bs[3 * b], b});
+            std::sort(o.begin(), o.end());
+            printf("   slowest / fastest blocks (dur ns, start ns, n, x, xcc, hw_id):\n");
+            for (int q = 0; q < 12; ++q) {
+                const int b = q < 8 ? o[o.size() - 1 - q].second : o[q - 8].second;
+                printf("     %llu %llu n=%d x=%d xcc=%llu hwid=%llx\n", (bs[3 * b + 1] - bs[3 * b]) * 10, (bs[3 * b] - s_min) * 10, b / (2 * ngrp), b % (2 * ngrp),
+                       bs[3 * b + 2] >> 32, bs[3 * b + 2] & 0xffffffffull);
+            }
+        }
+        printf("   blocks: starts spread %llu ns, first end %llu, last end %llu (from first start); duration dWn min/med/max %llu/%llu/%llu, dFq %llu/%llu/%llu ns\n",
+               (s_max - s_min) * 10, (e_min - s_min) * 10, (e_max - s_min) * 10, dur[0].front() * 10, dur[0][dur[0].size() / 2] * 10, dur[0].back() * 10,
+               dur[1].front() * 10, dur[1][dur[1].size() / 2] * 10, dur[1].back() * 10);
     }
     return 0;
 }
