@@ -211,6 +211,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     chain_tail();
 }
 
+// (148 VGPRs, 3 waves per SIMD; forcing 4 with amdgpu_waves_per_eu spills 38 registers and runs 30 % slower)
 template <typename T>
 __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
                                                             const int64_t* __restrict__ Ys,
@@ -245,7 +246,12 @@ struct CoefArgs {
     float Pf, eps;
 };
 
-template <typename T, int NSLT>      // NSLT = C/16 for the sliced chain, 0: coef is given
+// NT: non-temporal stores.  A dFs stream larger than the 256 MB last-level cache leaves that cache full of dirty
+// lines whose write-back the NEXT streaming kernel pays for (the pooling kernel of the next step: 117 us after a
+// cached 344 MB dFs stream, 89 us otherwise; scripts/diag/pool_after_dfs.py); sent around the cache the stream
+// costs this kernel 10 us more and the next one 26 us less.  Below that size the cache absorbs the stream and
+// cached stores are faster for both (the launcher picks).
+template <typename T, int NSLT, bool NT = false>      // NSLT = C/16 for the sliced chain, 0: coef is given
 __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ mask, const float* __restrict__ coef,
                                                     T* __restrict__ dFs, int C, int P, int rows_per_block, int b,
                                                     int cblk, float* sm, const CoefArgs& ca) {
@@ -326,7 +332,8 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(k * m[e]);
             }
-            rv[i] = v;
+            if constexpr (NT) __builtin_nontemporal_store(v, rv + i);
+            else rv[i] = v;
         }
         const int t0 = head + nvec * V;
         if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[t0 + lane]);

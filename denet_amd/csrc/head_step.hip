@@ -103,13 +103,13 @@ __global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a
         proto_extend_bwd_params_body(pa, 3, blockIdx.x - nchain, sm);     // dweight: needs only B1's slabs
 }
 
-template <typename T, int NSLT>
+template <typename T, int NSLT, bool NT>
 __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, CoefArgs ca, const float* __restrict__ mask,
                                                            T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bx = blockIdx.x, nms = gridDim.x - 3 * gx;
     if (bx < nms) {
-        masked_sum_bwd_body<T, NSLT>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
+        masked_sum_bwd_body<T, NSLT, NT>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
     } else {
         const int r = bx - nms;
         proto_extend_bwd_params_body(pa, r / gx, r % gx, sm);
@@ -367,13 +367,20 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-#define TAIL_GO(TT, NSLT)                                                                                     \
-    hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, (int)C, \
-                       (int)P, rpb, ncb, gx)
+        // dFs streams that do not fit the 256 MB last-level cache go around it (dev_masked_sum.hpp, NT);
+        // measured break-even between C5 (269 MB of bf16: cached stores win) and C3 (344 MB of fp32: NT wins)
+        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)320 << 20);
+#define TAIL_GO(TT, NSLT)                                                                                           \
+    if (nt)                                                                                                         \
+        hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, true>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs,  \
+                           (int)C, (int)P, rpb, ncb, gx);                                                           \
+    else                                                                                                            \
+        hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, false>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, \
+                           (int)C, (int)P, rpb, ncb, gx)
         if (f32) {
-            if (C == 256) TAIL_GO(float, 16); else TAIL_GO(float, 4);
+            if (C == 256) { TAIL_GO(float, 16); } else { TAIL_GO(float, 4); }
         } else {
-            if (C == 256) TAIL_GO(unsigned short, 16); else TAIL_GO(unsigned short, 4);
+            if (C == 256) { TAIL_GO(unsigned short, 16); } else { TAIL_GO(unsigned short, 4); }
         }
 #undef TAIL_GO
         DENET_CHECK_LAUNCH();

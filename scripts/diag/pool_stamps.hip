@@ -11,6 +11,7 @@ int denet_ensure_dynamic_lds(const void* kernel, size_t bytes) {
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 40, C = 256, h = 41, w = 41, H = 321, W = 321, P = h * w;
     const int chain = argc > 2 ? atoi(argv[2]) : 1;
+    const double binw = argc > 3 ? atof(argv[3]) : 1.0;   // histogram bin width, us
     float *Fs, *mask, *cnt, *S, *W1, *pre1;
     int64_t* Ys;
     CK(hipMalloc(&Fs, (size_t)B * C * P * 4)); CK(hipMemset(Fs, 0, (size_t)B * C * P * 4));
@@ -37,9 +38,9 @@ int main(int argc, char** argv) {
             int hs[32] = {0}, he[32] = {0}; double dur = 0;
             for (size_t b = 0; b < nblk; ++b) {
                 const double s0 = (bs[3 * b] - t0) * 0.01, e = (bs[3 * b + 1] - t0) * 0.01;
-                hs[(int)s0 < 31 ? (int)s0 : 31]++; he[(int)e < 31 ? (int)e : 31]++; dur += e - s0;
+                hs[(int)(s0 / binw) < 31 ? (int)(s0 / binw) : 31]++; he[(int)(e / binw) < 31 ? (int)(e / binw) : 31]++; dur += e - s0;
             }
-            printf("blocks=%zu mean dur %.1f us\n  start hist (1us bins):", nblk, dur / nblk);
+            printf("blocks=%zu mean dur %.1f us -> mean resident blocks %.0f\n  start hist (%.1f us bins):", nblk, dur / nblk, dur / (ms * 1e3), binw);
             for (int i = 0; i < 24; ++i) printf(" %d", hs[i]);
             printf("\n  end hist:");
             for (int i = 0; i < 24; ++i) printf(" %d", he[i]);
