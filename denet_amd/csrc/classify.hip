@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void classify_fwd_kernel(const T* __restri
 // ---------------------------------------------------------------------------
 #define CLW_NLD 16         // k-steps (pairs of channels) per chunk
 template <typename T, int RT, bool BUILD, int CJ>
-__global__ __launch_bounds__(256) void classify_fwd_wide_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
+__global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
                                                                int64_t wn_stride, const int64_t* __restrict__ labels,
                                                                int way, int K, int P, int base,
                                                                float* __restrict__ logits, float* __restrict__ bin,
@@ -549,6 +549,208 @@ __global__ __launch_bounds__(256) void classify_fwd_wide_kernel(const T* __restr
     STAMP(4);
 }
 
+// K > 32: the MFMA work of an episode is spread over as many CUs as there are (one block per CU: Wn[n] takes
+// 32 RT rows of LDS) and, inside a block, evenly over the four SIMDs.  A block owns a contiguous range of
+// 32-POSITION half tiles of one episode, the ranges cut so that N x groups ~ 256 blocks (C3: 12 blocks of 4-5 half
+// tiles per episode; C5: 32 of 6-7).  The unit of work is (half tile, 32-row tile of Wn) = 128 MFMAs; the waves
+// take the block's units round-robin, so a SIMD carries ceil(units / 4) x 128 MFMAs whatever the range length (a
+// wave per half tile put 768 on the SIMD that got two of them).  A = Wn rows from LDS, B = 32 positions of Fq,
+// one dword per lane and k-step (lane = position j, k half hh), the first chunk of the next unit requested under
+// the last MFMAs of the current one; logits straight from the accumulators; the binary logits need the
+// maximum over ALL rows of a position, so every unit leaves its top two (and the rows the ways name) in LDS and
+// the block merges them after a barrier.
+#ifndef CLW_NW
+#define CLW_NW 8
+#endif
+#define CLW_MAXH 8            // half tiles per block, at most
+#define CLW_XM(RT) (CLW_MAXH * (RT) * 64)                   // floats: [half tile][rt][m1, m2][32]
+template <typename T, int RT, bool BUILD, int CJ>
+__global__ __launch_bounds__(64 * CLW_NW) void classify_fwd_wide_kernel(const T* __restrict__ Fq, const float* __restrict__ Wn,
+                                                                      int64_t wn_stride, const int64_t* __restrict__ labels,
+                                                                      int way, int K, int P, int base,
+                                                                      float* __restrict__ logits, float* __restrict__ bin,
+                                                                      WnBuild wb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = 64 * CJ, NT = 64 * CLW_NW;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ldw = C + 1;
+    const int nht = (P + 31) >> 5;                 // half tiles of the episode
+    const int h0 = (int)((int64_t)blockIdx.x * nht / gridDim.x), h1 = (int)((int64_t)(blockIdx.x + 1) * nht / gridDim.x);
+    const int nh = h1 - h0, U = nh * RT;           // the host guarantees nh <= CLW_MAXH
+    float* xm = sm + 32 * RT * ldw;                // [nh][RT][2][32]
+    float* xf = xm + CLW_XM(RT);                   // [nh][way + 1][32]: the rows the ways name, and row 0
+    const T* fqn = Fq + (int64_t)n * C * P;
+
+    // The wave's work is a flat sequence of chunks (16 k-steps = 32 channels of one unit), G = units x C/32 of
+    // them.  Four chunk buffers form a ring: the B operand of chunk g+3 is requested before the MFMAs of chunk g,
+    // so a load has 48 MFMAs (~1.3 us, twice that with the SIMD's other wave) to arrive -- with one chunk of
+    // distance the waves sat in s_waitcnt (38 ns per MFMA against 27.5).  Columns are independent: a clamped
+    // column (past P) is computed and dropped; chunk indices past G re-request the last chunk (no branch
+    // around a load).
+    constexpr int CH = 2 * CLW_NLD, CPU = C / CH;  // channels per chunk, chunks per unit (8, or 2 at C = 64)
+    const int nu = wave < U ? (U - wave + CLW_NW - 1) / CLW_NW : 0, G = nu * CPU;
+    float b0[CLW_NLD], b1[CLW_NLD], b2[CLW_NLD], b3[CLW_NLD];
+    // 32-bit element offsets from the episode's base (C * P < 2^31): one v_add per load instead of a 64-bit
+    // multiply-add (quarter rate) and a 64-bit shift-add, which cost more issue time than the MFMAs they fed
+    const unsigned P2 = 2u * (unsigned)P;
+    auto issue = [&](int g, float (&x)[CLW_NLD]) {
+        const int gg = max(min(g, G - 1), 0);
+        const int u = min(wave + (gg / CPU) * CLW_NW, U - 1), c = (gg % CPU) * CH;
+        unsigned off = (unsigned)(c + hh) * (unsigned)P + (unsigned)min((h0 + u / RT) * 32 + j, P - 1);
+#pragma unroll
+        for (int q = 0; q < CLW_NLD; ++q) {
+#ifdef DENET_DIAG_NO_FQ
+            x[q] = 0.f;
+#else
+            x[q] = FeatIO<T>::load(fqn + off);
+#endif
+            off += P2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    STAMP(0);
+    issue(0, b0);                                  // in flight under the Wn staging
+    issue(1, b1);
+    issue(2, b2);
+
+    // (two passes of 2 RT quads per thread: one pass of 4 RT spills beside the three chunks in flight)
+    stage_wn<BUILD, NT, C / 16, (32 * RT * C / 8 + NT - 1) / NT>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
+    // rows K .. 32*RT-1 of the LDS image are zeros: the MFMA A operand needs no row mask
+    for (int i = K * ldw + tid; i < 32 * RT * ldw; i += NT) sm[i] = 0.f;
+    __syncthreads();
+    if constexpr (BUILD) {
+        float* dst = wb.Wn_out + (int64_t)n * K * C;
+        for (int k = blockIdx.x; k < K; k += gridDim.x)
+            for (int c = tid; c < C; c += NT) dst[k * C + c] = sm[k * ldw + c];
+    }
+    STAMP(1);
+
+    float* lg = logits + (int64_t)n * K * P;
+    // Four accumulators, one per k-step mod 4 (independent chains).  With the Fq loads stubbed out the loop runs
+    // at 72 cycles per MFMA and SIMD (66 is the pipe's rate), with them at 96: what bounds the kernel is the
+    // matrix work per SIMD, ceil(units / 4) x 128 MFMAs, plus the time its loads take to issue
+    // (scripts/diag/classify_stamps.hip, -DDENET_DIAG_NO_FQ); one, two or four chains measured the same.
+    f32x16 accs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[a][e] = 0.f;
+    auto mfma_chunk = [&](int g, const float (&x)[CLW_NLD]) {
+        if (g >= G) return;                        // uniform (C = 64 only: G need not be a multiple of 4)
+        const int u = wave + (g / CPU) * CLW_NW, c = (g % CPU) * CH;
+        const int arow = (32 * (u % RT) + j) * ldw + c + hh;
+        float av[CLW_NLD];
+#pragma unroll
+        for (int q = 0; q < CLW_NLD; ++q) av[q] = sm[arow + 2 * q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CLW_NLD; ++q)
+            accs[q & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], x[q], accs[q & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the unit whose last chunk is g is complete: logits from the accumulators, its share of the binary logits
+    auto finish_unit = [&](int g) {
+        if (g >= G || (g % CPU) != CPU - 1) return;          // uniform
+        const int u = wave + (g / CPU) * CLW_NW;
+        const int hl = u / RT, rt = u - hl * RT;
+        const int p = (h0 + hl) * 32 + j;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc[e] = (accs[0][e] + accs[1][e]) + (accs[2][e] + accs[3][e]);
+            accs[0][e] = 0.f; accs[1][e] = 0.f; accs[2][e] = 0.f; accs[3][e] = 0.f;
+        }
+        // ---- logits: 32 lanes = 128 contiguous bytes of a row ----
+        if (p < P) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (row < K) lg[(int64_t)row * P + p] = acc[e];
+            }
+        }
+        if (bin != nullptr) {
+            // this unit's largest and second largest entry per position (ties count: two equal maxima give
+            // m2 == m1), merged across the two lane halves
+            float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const float v = row < K ? acc[e] : -INFINITY;
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, v);       // second largest of {m1 >= m2, v}
+                m1 = fmaxf(m1, v);
+            }
+            const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+            const float hi = fmaxf(m1, o1), lo = fminf(m1, o1);
+            m2 = fmaxf(lo, fmaxf(m2, o2));
+            m1 = hi;
+            if (hh == 0) {
+                xm[((hl * RT + rt) * 2 + 0) * 32 + j] = m1;
+                xm[((hl * RT + rt) * 2 + 1) * 32 + j] = m2;
+            }
+            // the rows the ways name (and row 0 for base == 0), if this unit holds them
+            for (int s = 0; s <= way; ++s) {
+                int64_t sel = 0;
+                if (s < way) sel = labels[(int64_t)n * way + s];
+                else if (base) continue;
+                if (sel < 32 * rt || sel >= 32 * rt + 32 || sel >= K) continue;           // uniform
+                const int r = (int)sel & 31, idx = (r & 3) + 4 * (r >> 3), half = (r >> 2) & 1;
+                float v0 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (idx == e) v0 = acc[e];                                            // uniform branch
+                const float w0 = __shfl_xor(v0, 32, 64);
+                if (hh == 0) xf[(hl * (way + 1) + s) * 32 + j] = half == 0 ? v0 : w0;
+            }
+        }
+    };
+#pragma unroll 1
+    for (int g = 0; g < G; g += 4) {
+        issue(g + 3, b3);
+        mfma_chunk(g, b0);
+        issue(g + 4, b0);
+        mfma_chunk(g + 1, b1);
+        if constexpr (CPU == 2) finish_unit(g + 1);
+        issue(g + 5, b1);
+        mfma_chunk(g + 2, b2);
+        issue(g + 6, b2);
+        mfma_chunk(g + 3, b3);
+        finish_unit(g + 3);
+    }
+    STAMP(2);
+    if (bin == nullptr) return;
+    __syncthreads();
+    STAMP(3);
+    // ---- binary logits (utils/operations.py:327-337): ch1 = the label's row, ch0 = max over the other rows =
+    // the second largest entry if the label row holds the maximum (fg == m1), else the largest ----
+    for (int i = tid; i < nh * 32; i += NT) {
+        const int hl = i >> 5, jj = i & 31;
+        const int p = (h0 + hl) * 32 + jj;
+        if (p >= P) continue;
+        float m1 = xm[(hl * RT * 2 + 0) * 32 + jj], m2 = xm[(hl * RT * 2 + 1) * 32 + jj];
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt) {
+            const float b1 = xm[((hl * RT + rt) * 2 + 0) * 32 + jj], b2 = xm[((hl * RT + rt) * 2 + 1) * 32 + jj];
+            const float hi = fmaxf(m1, b1), lo = fminf(m1, b1);
+            m2 = fmaxf(lo, fmaxf(m2, b2));
+            m1 = hi;
+        }
+        for (int jw = 0; jw < way; ++jw) {
+            const int64_t lab64 = labels[(int64_t)n * way + jw];
+            const bool labok = lab64 >= 0 && lab64 < K;
+            const float fg = labok ? xf[(hl * (way + 1) + jw) * 32 + jj] : 0.f;
+            float outb;
+            if (base) outb = (labok && fg == m1) ? m2 : m1;
+            else outb = xf[(hl * (way + 1) + way) * 32 + jj];
+            float* dst = bin + ((int64_t)(n * way + jw) * 2) * P + p;
+            dst[0] = outb;
+            dst[P] = fg;
+        }
+    }
+    STAMP(4);
+}
+
 // ---------------------------------------------------------------------------
 // K3e stand-alone: get_binary_logits on an existing logits tensor (utils/operations.py:313-338)
 // and the batch mean of extended weights for mode='deploy' (model/common.py:369-372).
@@ -601,11 +803,43 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
     if (RT >= 2) {
-        // K > 32: Wn[n] resident for four position tiles per block (classify_fwd_wide_kernel)
-        const size_t ldsw = (size_t)32 * RT * (C + 1) * 4;          // rows K .. 32*RT-1 are zero padding
+        // K > 32: Wn[n] resident in LDS.  Two layouts: (a) units of (32-position half tile, 32-row tile) dealt to
+        // 8 waves, N x groups ~ 256 blocks -- a SIMD carries ceil(units / 4) x 128 MFMAs; (b) a wave per 64-position
+        // tile and four tiles per block -- 768 MFMAs per SIMD at RT = 3, but every Fq element loaded once, 8 bytes
+        // per lane (layout (a) reads it RT times, 4 bytes per lane).  (a) where it takes the matrix work per SIMD
+        // to two thirds or less (C3: 512 against 768, F3 46 -> 39 us), (b) otherwise (C5: 768 either way, and
+        // (a) measured 51 us against 48).
+        const int64_t nht = (P + 31) / 32;
+        int64_t groups = 256 / N;
+        if (groups > nht) groups = nht;
+        if (groups < (nht + CLW_MAXH - 1) / CLW_MAXH) groups = (nht + CLW_MAXH - 1) / CLW_MAXH;
+        const int64_t units = ((nht + groups - 1) / groups) * RT;
+        const bool by_units = ((units + 3) / 4) * 128 * 3 <= (int64_t)RT * 256 * 2;
+        if (!by_units) {
+            const size_t lds4 = (size_t)32 * RT * (C + 1) * 4;          // rows K .. 32*RT-1 are zero padding
+            if (lds4 > 160 * 1024 || RT > 4) return DENET_E_UNSUPPORTED;
+            const int ntile = (int)((P + CL_TP - 1) / CL_TP);
+            dim3 grid4((unsigned)((ntile + 3) / 4), (unsigned)N), block4(256);
+#define CL_WIDE4(R, J)                                                                                        \
+    {                                                                                                         \
+        int rc = set_lds(classify_fwd_wide4_kernel<T, R, BUILD, J>, lds4);                                    \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((classify_fwd_wide4_kernel<T, R, BUILD, J>), grid4, block4, lds4, st, Fq, Wn, wn_stride, \
+                           labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
+    }
+            switch (RT) {
+                case 2: if (C == 64) CL_WIDE4(2, 1) else CL_WIDE4(2, 4) break;
+                case 3: if (C == 64) CL_WIDE4(3, 1) else CL_WIDE4(3, 4) break;
+                default: if (C == 64) CL_WIDE4(4, 1) else CL_WIDE4(4, 4) break;
+            }
+#undef CL_WIDE4
+            DENET_CHECK_LAUNCH();
+            return DENET_OK;
+        }
+        // LDS: Wn[n] (rows K .. 32*RT-1 zero padding) + the per-unit top-two and label rows for the binary logits
+        const size_t ldsw = ((size_t)32 * RT * (C + 1) + CLW_XM(RT) + (size_t)CLW_MAXH * (way + 1) * 32) * 4;
         if (ldsw > 160 * 1024 || RT > 4) return DENET_E_UNSUPPORTED;
-        const int ntile = (int)((P + CL_TP - 1) / CL_TP);
-        dim3 gridw((unsigned)((ntile + 3) / 4), (unsigned)N), blockw(256);
+        dim3 gridw((unsigned)groups, (unsigned)N), blockw(64 * CLW_NW);
 #define CL_WIDE(R, J)                                                                                         \
     {                                                                                                         \
         int rc = set_lds(classify_fwd_wide_kernel<T, R, BUILD, J>, ldsw);                                     \

@@ -4,6 +4,9 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 #include <cstdlib>
+int denet_ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 8, way = argc > 2 ? atoi(argv[2]) : 1, K = argc > 3 ? atoi(argv[3]) : 21, C = 256, P = argc > 4 ? atoi(argv[4]) : 1681;
     float *Fq, *Wn, *logits, *bin; int64_t* labels;
