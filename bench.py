@@ -253,6 +253,11 @@ def main():
     # of torch's object graph (measured 42 ms, once) would be charged to whichever step triggers it
     gc.collect()
     gc.disable()
+    # the W warm-up steps run HERE, right before the timed region: the breakdown pass and the collection above
+    # leave the GPU idle for tens of milliseconds, and the first steps after an idle period run below the
+    # sustained clocks (20 timed steps read 95.3 us/step after the idle gap, 90.5 us in a 300-step run)
+    for _ in range(max(args.warmup, 2)):
+        runner()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
