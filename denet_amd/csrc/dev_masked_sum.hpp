@@ -28,7 +28,9 @@ template <> struct Vec16<unsigned short> {
 // Body of K1 for block (cblk, b): `sm` [P] floats of LDS.  With Ys != nullptr the mask is gathered
 // here from the int64 label map (K0 fused: nearest resize, model/common.py:189-190) and the block
 // with cblk == 0 also writes mask[b,:] and cnt[b] for the backward pass; otherwise it is read from `mask`.
-template <typename T>
+// LONG: rows of more than 512 vectors (P > 2048 fp32 / 4096 bf16 elements) -- a separate instantiation, so that
+// the register sets of the two streaming loops do not add up in one kernel.
+template <typename T, bool LONG = false>
 __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, const int64_t* __restrict__ Ys,
                                                     float* __restrict__ mask, float* __restrict__ cnt,
                                                     float* __restrict__ S, int C, int P, int rows_per_block, int H,
@@ -59,7 +61,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
     constexpr int NR = 2;                                 // rows of a wave in flight together (more costs occupancy)
-    const bool short_rows = (P / V) <= NV * 64;           // P <= 2048 fp32 / 4096 bf16 elements
+    constexpr bool short_rows = !LONG;                    // the launcher picks: P / V <= NV * 64
 
     // ---- fast path, part 1: EVERY feature load of the wave's first NR rows is issued before anything
     // else -- they do not depend on the mask -- all unconditional (clamped index, value selected later:
@@ -132,7 +134,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             pre1_part[((int64_t)b * ncb + cblk) * C + o] = mine;
         }
     };
-    if (short_rows) issue(wave);
+    if constexpr (short_rows) issue(wave);
     // ---- the mask: gathered here from the int64 label map (K0 fused: nearest resize,
     // model/common.py:189-190; the block with cblk == 0 also writes mask[b,:] and cnt[b] for the backward
     // pass), or read from `mask`.
@@ -162,7 +164,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     }
     __syncthreads();
 
-    if (short_rows) {
+    if constexpr (short_rows) {
         consume(wave);
         bool fetched = false;
         for (int r = wave + 4 * NR; r < rows_per_block; r += 4 * NR) {
@@ -173,7 +175,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         if (!fetched) fetch_w1();
         chain_tail();
         return;
-    }
+    } else {
     // ---- long rows: stream each row with a rolling loop
     fetch_w1();
     for (int r = wave; r < rows_per_block; r += 4) {
@@ -189,17 +191,28 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
         const int t0 = head + nvec * V;
         const float tv1 = FeatIO<T>::load(row + min(t0 + lane, P - 1));
-        // eight clamped, unconditional vector loads in flight per lane and trip (8 KB per wave)
-        for (int i0 = lane; i0 < nvec; i0 += 64 * NV) {
-            vec_t vv[NV];
+        // eight clamped, unconditional vector loads per lane and trip (8 KB per wave), the NEXT trip's loads
+        // requested before the current trip is consumed (two register sets): a wave that waits for every trip
+        // before it asks for the next one streams at one trip per memory round trip
+        vec_t va[NV], vb[NV];
+        auto fetch = [&](int i0, vec_t (&vv)[NV]) {
 #pragma unroll
-            for (int u = 0; u < NV; ++u) vv[u] = rv[min(i0 + 64 * u, nvec - 1)];
+            for (int u = 0; u < NV; ++u) vv[u] = rv[max(min(i0 + 64 * u, nvec - 1), 0)];
+        };
+        auto eat = [&](int i0, const vec_t (&vv)[NV]) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int i = i0 + 64 * u;
-                const float d = Vec16<T>::dot(vv[u], sm + head + min(i, nvec - 1) * V);
+                const float d = Vec16<T>::dot(vv[u], sm + head + max(min(i, nvec - 1), 0) * V);
                 acc += (i < nvec) ? d : 0.f;
             }
+        };
+        fetch(lane, va);
+        for (int i0 = lane; i0 < nvec; i0 += 2 * 64 * NV) {
+            fetch(i0 + 64 * NV, vb);
+            eat(i0, va);
+            fetch(i0 + 2 * 64 * NV, va);
+            eat(i0 + 64 * NV, vb);
         }
         acc += (t0 + lane < P) ? tv1 * sm[min(t0 + lane, P - 1)] : 0.f;
         acc = wave_sum(acc);
@@ -209,10 +222,12 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         }
     }
     chain_tail();
+    }
 }
 
-// (148 VGPRs, 3 waves per SIMD; forcing 4 with amdgpu_waves_per_eu spills 38 registers and runs 30 % slower)
-template <typename T>
+// (short rows, fp32: 134 VGPRs, 3 waves per SIMD; forcing 4 with amdgpu_waves_per_eu spills 7 registers and the
+// stream runs 10 % slower at every batch size: more resident blocks do not buy bandwidth)
+template <typename T, bool LONG>
 __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
                                                             const int64_t* __restrict__ Ys,
                                                             float* __restrict__ mask, float* __restrict__ cnt,
@@ -225,8 +240,8 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
     const int ncb = (C + rows_per_block - 1) / rows_per_block;
     const int v = xcd_swizzle(blockIdx.x, gridDim.x);
     BSTAMP(0);
-    masked_sum_fwd_body<T>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
-                           pre1_part);
+    masked_sum_fwd_body<T, LONG>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
+                                 pre1_part);
     BSTAMP(1);
 }
 

@@ -57,6 +57,23 @@ extern "C" int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_
 #endif
 static inline int pick_rows_per_block(int64_t C) { return C >= DENET_RPB ? DENET_RPB : (int)C; }
 
+// the pooling kernel: short rows (up to 512 16-byte vectors: whole rows in flight) or long rows (rolling loop)
+static void launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float* mask, float* cnt, float* S, int C, int P,
+                        int rpb, int H, int W, int h, int w, const float* W1, float* pre1_part, dim3 grid, size_t lds,
+                        hipStream_t st) {
+    const bool f32 = feat_dtype == DENET_F32;
+    const bool longr = P / (f32 ? 4 : 8) > 512;
+#define POOL_GO(TT, LG)                                                                                           \
+    hipLaunchKernelGGL((masked_sum_fwd_kernel<TT, LG>), grid, dim3(256), lds, st, (const TT*)Fs, Ys, mask, cnt, S, C, P, \
+                       rpb, H, W, h, w, W1, pre1_part)
+    if (f32) {
+        if (longr) POOL_GO(float, true); else POOL_GO(float, false);
+    } else {
+        if (longr) POOL_GO(unsigned short, true); else POOL_GO(unsigned short, false);
+    }
+#undef POOL_GO
+}
+
 extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float* mask, int64_t B, int64_t C,
                                     int64_t P, float* S, void* stream) {
     if (!Fs || !mask || !S) return DENET_E_BADARG;
@@ -65,16 +82,9 @@ extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float*
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
     size_t lds = (size_t)P * 4 + 32 + 64;
-    if (feat_dtype == DENET_F32)
-        hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
-                           (const float*)Fs, (const int64_t*)nullptr, (float*)mask, (float*)nullptr, S, (int)C,
-                           (int)P, rpb, 0, 0, 0, 0, (const float*)nullptr, (float*)nullptr);
-    else if (feat_dtype == DENET_BF16)
-        hipLaunchKernelGGL(masked_sum_fwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream,
-                           (const unsigned short*)Fs, (const int64_t*)nullptr, (float*)mask, (float*)nullptr, S,
-                           (int)C, (int)P, rpb, 0, 0, 0, 0, (const float*)nullptr, (float*)nullptr);
-    else
-        return DENET_E_UNSUPPORTED;
+    if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
+    launch_pool(Fs, feat_dtype, nullptr, (float*)mask, nullptr, S, (int)C, (int)P, rpb, 0, 0, 0, 0, nullptr, nullptr, grid, lds,
+                (hipStream_t)stream);
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -126,16 +136,9 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
         if (rc) return rc;
         Ys = nullptr;
     }
-    if (feat_dtype == DENET_F32)
-        hipLaunchKernelGGL(masked_sum_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream,
-                           (const float*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w,
-                           W1, pre1_part);
-    else if (feat_dtype == DENET_BF16)
-        hipLaunchKernelGGL(masked_sum_fwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream,
-                           (const unsigned short*)Fs, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h,
-                           (int)w, W1, pre1_part);
-    else
-        return DENET_E_UNSUPPORTED;
+    if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
+    launch_pool(Fs, feat_dtype, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w, W1, pre1_part, grid,
+                lds, (hipStream_t)stream);
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
