@@ -27,6 +27,8 @@ def sweep(seed=0, count=24, verbose=True):
     worst, failures = {}, []
     for it in range(count):
         h, w = rng.randint(3, 12), rng.randint(3, 14)
+        if rng.random() < 0.25:                                     # several position tiles / tile groups, ragged last tile
+            h, w = rng.randint(15, 45), rng.randint(15, 45)
         if rng.random() < 0.5:                                      # power-of-two scale: (H-1) = (h-1) * 2^j
             j = rng.choice([1, 2, 3])
             H, W = (h - 1) * 2 ** j + 1, (w - 1) * 2 ** rng.choice([1, 2, 3]) + 1
