@@ -150,9 +150,9 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         }
     }
     if (!found) return false;
-    // chain path: cells of at most 16 label columns, the (row, cell) items of a block in one round of
-    // thread pairs, and a table chunk that keeps the block within ~40 KB of LDS (four blocks per CU) if
-    // it can, within 64 KB otherwise
+    // chain path: cells of 8 or 9 label columns, the (row, cell) items of a block in one round of
+    // thread pairs, and a table chunk that keeps the block within 40-52 KB of LDS (four / three blocks per CU)
+    // if it can, within 64 KB otherwise
     g->em = 0;
     g->kchunk = 0;
     g->lds_chain = 0;
@@ -161,7 +161,14 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
         const size_t fb = exact_lds(K, g->ncmax, rows_max, emax, g->xw_max, grad, 1);
         int best = 0;
         for (int pass = 0; pass < 2 && !best; ++pass) {
-            const size_t cap = pass == 0 ? 40 * 1024 : 64 * 1024;
+            // first try: 52 KB (three blocks per CU) for 8-column cells, 40 KB (four blocks) for 9-column cells.
+            // Measured at K = 81: 41 -> 321 (C3) runs 5 chunks of 18 classes in 40 KB and 3 chunks of 28 in 52 KB,
+            // F4 107 -> 87 us; 81 -> 642 (C5) 6 chunks of 14 against 4 of 22, 139 -> 144 us; 64 KB (two blocks per
+            // CU) equals the 40 KB figure in both.  K <= 32 fits one chunk in 40 KB either way.
+#ifndef DENET_WCE_CAP_KB
+#define DENET_WCE_CAP_KB (emax <= 8 ? 52 : 40)
+#endif
+            const size_t cap = pass == 0 ? (size_t)DENET_WCE_CAP_KB * 1024 : 64 * 1024;
             for (int kc = K; kc >= (K < 8 ? K : 8); --kc) {
                 if ((kc & 1) && kc != K) continue;          // class pairs must not straddle chunks
                 const size_t b = (size_t)wc_lds_floats(K, g->ncmax, rows_max, kc, em, grad) * 4;

@@ -73,7 +73,7 @@ def short(name):
 
 def find(d, pat):
     f = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None        # a directory may hold several runs: the newest
 
 
 def pmc_mean(d, counter):
