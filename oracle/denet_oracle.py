@@ -56,16 +56,16 @@ def bilinear_taps(out_size: int, in_size: int):
 # --------------------------------------------------------------------------
 # K1: mask resize + masked pooling      (model/common.py:188-198, 234-246)
 # --------------------------------------------------------------------------
-def resize_mask(Ys: torch.Tensor, h: int, w: int) -> torch.Tensor:
+def resize_mask(Ys: torch.Tensor, h: int, w: int, dtype=torch.float32) -> torch.Tensor:
     """[B,H,W] int -> [B,1,h,w] float, nearest."""
-    return F.interpolate(Ys.unsqueeze(1).float(), size=(h, w), mode="nearest")
+    return F.interpolate(Ys.unsqueeze(1).to(dtype), size=(h, w), mode="nearest")
 
 
 def gam_attention(Fs: torch.Tensor, Ys: torch.Tensor) -> torch.Tensor:
     """att = mean over all h*w positions of mask*Fs  -> [B,c,1,1]
     (GAM.forward, model/common.py:241-243)."""
     h, w = Fs.shape[-2:]
-    return F.adaptive_avg_pool2d(resize_mask(Ys, h, w) * Fs, (1, 1))
+    return F.adaptive_avg_pool2d(resize_mask(Ys, h, w, Fs.dtype) * Fs, (1, 1))
 
 
 def gate(att, p, gate_mask=None):
@@ -82,7 +82,7 @@ def gate(att, p, gate_mask=None):
 def masked_avg_pool_project(Fs_g, Ys, p):
     """(sum(mask*F)/(sum(mask)+1e-3)) -> 1x1 conv   (model/common.py:188-196)."""
     h, w = Fs_g.shape[-2:]
-    m = resize_mask(Ys, h, w)
+    m = resize_mask(Ys, h, w, Fs_g.dtype)
     num = torch.sum(m * Fs_g, dim=(2, 3), keepdim=True)
     den = torch.sum(m, dim=(2, 3), keepdim=True)
     proto = num / (den + EPS_POOL)
@@ -179,39 +179,43 @@ def weighted_ce_2d(up, target, weight=None):
     return F.cross_entropy(x, target.reshape(-1), weight=weight, ignore_index=IGNORE)
 
 
-def loss_knowledge(full_up, Yq_full, wgt):
+def loss_knowledge(full_up, Yq_full, wgt, dtype=torch.float32):
     """mean over episodes of per-episode weighted CE (trainer/utils.py:270-277)."""
     N = full_up.shape[0]
     tot = 0.0
     for n in range(N):
-        tot = tot + weighted_ce_2d(full_up[n:n + 1].float(), Yq_full[n:n + 1].long(), wgt[n])
+        tot = tot + weighted_ce_2d(full_up[n:n + 1].to(dtype), Yq_full[n:n + 1].long(), wgt[n].to(dtype))
     return tot / N
 
 
-def loss_pattern(bin_up, Yq):
+def loss_pattern(bin_up, Yq, dtype=torch.float32):
     """binary focal loss, alpha .25 gamma 2 (loss/losses.py:47-79)."""
-    x = bin_up.float().permute(0, 2, 3, 1).reshape(-1, bin_up.shape[1])
+    x = bin_up.to(dtype).permute(0, 2, 3, 1).reshape(-1, bin_up.shape[1])
     t = Yq.long().reshape(-1)
     prob = F.softmax(x, dim=-1)
     foc = (1 - prob) ** FOCAL_GAMMA * torch.log(prob)
-    a = torch.tensor([FOCAL_ALPHA, 1 - FOCAL_ALPHA])
+    a = torch.tensor([FOCAL_ALPHA, 1 - FOCAL_ALPHA], dtype=dtype)
     return F.nll_loss(foc, t, weight=a, ignore_index=IGNORE)
 
 
 def head_step(Fq, Fs, Ys, label, Yq, Yq_full, wgt, p, gate_mask=None, weight_mask=None,
-              backward=True):
+              backward=True, dtype=torch.float32):
     """Everything the bench boundary covers: forward, both
     losses, and loss_k.backward() (trainer/trainers.py:951-975).  Returns a
-    dict with logits, losses and, if backward, grads of Fq, Fs and params."""
-    Fq = Fq.detach().float().requires_grad_(backward)
-    Fs = Fs.detach().float().requires_grad_(backward)
-    pp = {k: v.detach().clone().requires_grad_(backward) for k, v in p.items()}
+    dict with logits, losses and, if backward, grads of Fq, Fs and params.
+    dtype=torch.float64 runs the same lines in double: the yardstick for how far fp32 arithmetic in ANY
+    order sits from the exact result (tests use it to size the absolute floor of element-wise bounds)."""
+    Fq = Fq.detach().to(dtype).requires_grad_(backward)
+    Fs = Fs.detach().to(dtype).requires_grad_(backward)
+    pp = {k: v.detach().clone().to(dtype).requires_grad_(backward) for k, v in p.items()}
+    gate_mask = None if gate_mask is None else gate_mask.to(dtype)
+    weight_mask = None if weight_mask is None else weight_mask.to(dtype)
     full, binl, Wn = head_forward(Fq, Fs, Ys, label, pp, gate_mask, weight_mask)
     size = Yq_full.shape[-2:]
     full_up = upsample(full, size)
-    bin_up = upsample(binl.float(), size)
-    lk = loss_knowledge(full_up, Yq_full, wgt)
-    lp = loss_pattern(bin_up, Yq.reshape(-1, *size))
+    bin_up = upsample(binl.to(dtype), size)
+    lk = loss_knowledge(full_up, Yq_full, wgt, dtype)
+    lp = loss_pattern(bin_up, Yq.reshape(-1, *size), dtype)
     out = dict(logits_full=full.detach(), logits_binary=binl.detach(), weights=Wn.detach(),
                full_up=full_up.detach(), bin_up=bin_up.detach(),
                loss_k=lk.detach(), loss_p=lp.detach())

@@ -341,3 +341,9 @@ def test_denet_bf16_features_from_the_producer(dev):
         full8, bin8 = m(Is8.to(dev), Ys8.to(dev), Iq8.to(dev), cls8.to(dev))
     assert full8.shape == (8, 21, 41, 41) and bin8.shape == (8, 2, 41, 41) and torch.isfinite(full8).all()
     assert m.vis["hidden_Fq"].dtype == torch.bfloat16
+
+
+def test_smoke_entry_point(dev):
+    """__graft_entry__.smoke() itself (the driver runs it before the bench): fused step vs the oracle."""
+    import __graft_entry__ as g
+    g.smoke()
