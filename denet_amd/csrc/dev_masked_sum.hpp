@@ -248,6 +248,15 @@ __global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict
 // ---------------------------------------------------------------------------
 // K1b: dFs[b,c,p] = mask[b,p] * coef[b,c]
 // ---------------------------------------------------------------------------
+// q = e / d, rem = e - q*d for 0 <= e < 2^22, 0 < d <= 2^14, inv = 1/d (float estimate + one-step correction)
+__device__ __forceinline__ int wc_divmod_p(int e, int d, float inv, int& rem) {
+    int q = (int)(((float)e + 0.5f) * inv);
+    int r = e - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
 // Sliced chain, last step (fused step only): the block forms coef[b][c0..c0+16) itself from the
 // split-K partials of the previous launch,
 //   dpre1[b][j] = (hidden[b][j] > 0) * sum_sl dh_part[b][sl][j]             (relu backward)
@@ -321,37 +330,95 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
             const float datt = ((red[t] + red[16 + t]) + red[32 + t]) + red[48 + t];
             coefs[t] = cd * (cg / cc) + datt / ca.Pf;
         }
+    } else {
+        if ((int)threadIdx.x < rows_per_block) coefs[threadIdx.x] = coef[(int64_t)b * C + min(c0 + (int)threadIdx.x, C - 1)];
     }
     __syncthreads();
 
     constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
-    for (int r = wave; r < rows_per_block; r += 4) {
-        const int c = c0 + r;
-        if (c >= C) break;
-        const float k = SLICED ? coefs[r] : coef[(int64_t)b * C + c];
-        T* row = dFs + ((int64_t)b * C + c) * P;
-        const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
-        int head = mis ? V - mis : 0;
-        if (head > P) head = P;
-        if (lane < head) FeatIO<T>::store(row + lane, k * sm[lane]);
-        const int nvec = (P - head) / V;
-        vec_t* rv = reinterpret_cast<vec_t*>(row + head);
+    if constexpr (!NT) {
+        // streams the last-level cache absorbs (C2, C5): one wave per channel row, four rows of a block in flight
+        // (measured against the flat writer below: 17.1 vs 17.7 us at C2, 69.4 vs 71.4 us at C5)
+        for (int r = wave; r < rows_per_block; r += 4) {
+            const int c = c0 + r;
+            if (c >= C) break;
+            const float k = coefs[r];
+            T* row = dFs + ((int64_t)b * C + c) * P;
+            const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
+            int head = mis ? V - mis : 0;
+            if (head > P) head = P;
+            if (lane < head) FeatIO<T>::store(row + lane, k * sm[lane]);
+            const int nvec = (P - head) / V;
+            vec_t* rv = reinterpret_cast<vec_t*>(row + head);
 #pragma unroll 4
-        for (int i = lane; i < nvec; i += 64) {
-            const float* m = sm + head + i * V;
-            vec_t v;
-            if constexpr (V == 4) {
-                v[0] = k * m[0]; v[1] = k * m[1]; v[2] = k * m[2]; v[3] = k * m[3];
-            } else {
+            for (int i = lane; i < nvec; i += 64) {
+                const float* m = sm + head + i * V;
+                vec_t v;
+                if constexpr (V == 4) {
+                    v[0] = k * m[0]; v[1] = k * m[1]; v[2] = k * m[2]; v[3] = k * m[3];
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(k * m[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(k * m[e]);
+                }
+                rv[i] = v;
             }
-            if constexpr (NT) __builtin_nontemporal_store(v, rv + i);
-            else rv[i] = v;
+            const int t0 = head + nvec * V;
+            if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[t0 + lane]);
+        }
+    } else {
+        // The block's 16 channel rows are ONE contiguous span of rows * P elements (NCHW): all 256 threads write it
+        // front to back, 4 KB per trip, instead of one wave per row (four 1 KB streams 6.7 KB apart per block and
+        // ~7000 of them in flight on the chip, every one opening a DRAM page of its own).  Element e of the span is
+        // coefs[e / P] * mask[e % P]; a 16-byte vector may straddle two rows.
+        const int rows = min(rows_per_block, C - c0);
+        const int total = rows * P;
+        T* out = dFs + ((int64_t)b * C + c0) * P;
+        const float invP = 1.f / (float)P;
+        auto value = [&](int e) {
+            int p;
+            const int r = wc_divmod_p(e, P, invP, p);
+            return coefs[r] * sm[p];
+        };
+        const int mis = (int)(((uintptr_t)out / sizeof(T)) % V);
+        int head = mis ? V - mis : 0;
+        if (head > total) head = total;
+        if ((int)threadIdx.x < head) FeatIO<T>::store(out + threadIdx.x, value(threadIdx.x));
+        const int nvec = (total - head) / V;
+        vec_t* ov = reinterpret_cast<vec_t*>(out + head);
+        // (row, position) of the thread's vector advance by 256 * V elements per trip: one divmod up front, then
+        // an add and a compare per trip; a vector that straddles two rows (one in ~P / V) takes the select path
+        int p0;
+        int r0 = wc_divmod_p(head + (int)threadIdx.x * V, P, invP, p0);
+        const int stepq = (256 * V) / P, stepr = 256 * V - stepq * P;
+#pragma unroll 2
+        for (int i = threadIdx.x; i < nvec; i += 256) {
+            const float k0 = coefs[min(r0, rows - 1)];
+            vec_t v;
+            if (p0 + V <= P) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float x = k0 * sm[p0 + e];
+                    if constexpr (V == 4) v[e] = x;
+                    else v[e] = f32_to_bf16(x);
+                }
+            } else {
+                const float k1 = coefs[min(r0 + 1, rows - 1)];
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const bool wrap = p0 + e >= P;
+                    const float x = (wrap ? k1 : k0) * sm[wrap ? p0 + e - P : p0 + e];
+                    if constexpr (V == 4) v[e] = x;
+                    else v[e] = f32_to_bf16(x);
+                }
+            }
+            __builtin_nontemporal_store(v, ov + i);
+            p0 += stepr;
+            r0 += stepq;
+            if (p0 >= P) { p0 -= P; ++r0; }
         }
         const int t0 = head + nvec * V;
-        if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[t0 + lane]);
+        if (t0 + (int)threadIdx.x < total) FeatIO<T>::store(out + t0 + threadIdx.x, value(t0 + threadIdx.x));
     }
 }
 

@@ -96,7 +96,7 @@ extern "C" int denet_masked_sum_bwd(const float* mask, const float* coef, int64_
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)((C + rpb - 1) / rpb), (unsigned)B);
-    size_t lds = (size_t)P * 4;
+    size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;     // mask row + the block's 16 coefficients
     if (feat_dtype == DENET_F32)
         hipLaunchKernelGGL(masked_sum_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, mask, coef,
                            (float*)dFs, (int)C, (int)P, rpb);
