@@ -130,8 +130,11 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     // The in-kernel gather touches one 64-byte sector of the label map per mask element, once per channel
     // block: C/16 times 64 P bytes per image against C P sF bytes of features.  At 41 x 41 that is cheaper
     // than a launch of its own; from P = 4096 on (81 x 81: 420 KB of sectors per block against 210 KB of bf16
-    // features) the mask is resized once per image first and the blocks read it back as P floats.
-    if (P >= 4096) {
+    // features) the mask is resized once per image first and the blocks read it back as P floats.  The same
+    // from 128 images on: the gather is 1681 scattered 8-byte loads per block, sixteen times per image, and
+    // costs the stream 15 us of 86 at 200 images (C3) and 40 of 258 at 640 (scripts/diag/pool_stamps: modes
+    // 1 / 0 / 2); the extra launch costs ~4 us, which only small batches cannot afford.
+    if (P >= 4096 || B >= 128) {
         int rc = denet_mask_resize(Ys, B, H, W, h, w, mask, cnt, stream);
         if (rc) return rc;
         Ys = nullptr;

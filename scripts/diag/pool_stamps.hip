@@ -21,12 +21,16 @@ int main(int argc, char** argv) {
     const size_t nblk = (size_t)B * 16;
     unsigned long long* d_bs; CK(hipMalloc(&d_bs, nblk * 24));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &d_bs, sizeof(d_bs)));
+    if (denet_mask_resize(Ys, B, H, W, h, w, mask, cnt, nullptr)) return 1;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipMemset(d_bs, 0, nblk * 24));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        int rc = denet_masked_pool_fwd_chain(Fs, DENET_F32, Ys, B, C, H, W, h, w, mask, cnt, S, chain ? W1 : nullptr, chain ? pre1 : nullptr, nullptr);
+        // chain: 1 = fused mask gather + split-K tail (the fused step's launch), 0 = gather, no tail,
+        //        2 = mask resized beforehand, pooling only (denet_masked_sum_fwd)
+        int rc = chain == 2 ? denet_masked_sum_fwd(Fs, DENET_F32, mask, B, C, h * w, S, nullptr)
+                            : denet_masked_pool_fwd_chain(Fs, DENET_F32, Ys, B, C, H, W, h, w, mask, cnt, S, chain ? W1 : nullptr, chain ? pre1 : nullptr, nullptr);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
