@@ -43,6 +43,7 @@
 // upsample_loss_body -- block-uniform branch, same outputs.
 #pragma once
 #include "dev_upsample_loss.hpp"
+#include <type_traits>
 
 #define WC_TAME (-120.f)
 // diagnostic builds only (scripts/diag/loss_bench.hip): leave the block after phase WC_STOP, to count the
@@ -187,6 +188,9 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
     __syncthreads();
 
     const float* src = logits + (int64_t)n * K * h * w;
+    // class weight of thread tid, requested with the logits (one round trip for all of the block's global operands)
+    float wv0 = 1.f;
+    if (wgt) wv0 = wgt[(int64_t)n * K + min(tid, K - 1)];
     {
         // thread <-> (class, column) by shifts (the column count rounded up to a power of two)
         const int xsh = 32 - __builtin_clz((unsigned)max(ncol - 1, 1));
@@ -197,24 +201,43 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
         const unsigned hw = (unsigned)(h * w);
         float m0 = -INFINITY, m1 = -INFINITY;
         bool nan = false;
-        for (int k = tid >> xsh; k < K; k += kstep) {
-            const unsigned o = (unsigned)k * hw + (unsigned)xc;
-            const float v0 = s0[o] * UL_LOG2E, v1 = s1[o] * UL_LOG2E;
-            if (x < ncol) {
-                raw0[k * ncmax + x] = v0;
-                raw1[k * ncmax + x] = v1;
+        // bursts of NB row pairs, clamped and unconditional, all requested before the first is used: a loop of
+        // load -> wait -> store costs one memory round trip per 256 >> xsh classes (six at K = 81)
+        auto stage = [&](auto nb) {
+            constexpr int NB = decltype(nb)::value;
+            for (int kk = tid >> xsh; kk < K + (tid >> xsh); kk += NB * kstep) {
+                float v0[NB], v1[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const unsigned o = (unsigned)min(kk + u * kstep, K - 1) * hw + (unsigned)xc;
+                    v0[u] = s0[o];
+                    v1[u] = s1[o];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int k = kk + u * kstep;
+                    const float a0 = v0[u] * UL_LOG2E, a1 = v1[u] * UL_LOG2E;
+                    if (x < ncol && k < K) {
+                        raw0[k * ncmax + x] = a0;
+                        raw1[k * ncmax + x] = a1;
+                    }
+                    nan = nan || (a0 != a0) || (a1 != a1);
+                    m0 = fmaxf(m0, a0);
+                    m1 = fmaxf(m1, a1);
+                }
             }
-            nan = nan || (v0 != v0) || (v1 != v1);
-            m0 = fmaxf(m0, v0);
-            m1 = fmaxf(m1, v1);
-        }
+        };
+        if (K <= 2 * kstep) stage(std::integral_constant<int, 2>{});
+        else if (K <= 4 * kstep) stage(std::integral_constant<int, 4>{});
+        else stage(std::integral_constant<int, 8>{});
         if (x < ncol && (tid >> xsh) < K) {
             atomicMax(&Mi[x], wc_enc(m0));
             atomicMax(&Mi[ncmax + x], wc_enc(m1));
         }
         if (nan) flag[0] = 1;
     }
-    for (int k = tid; k <= K; k += UL_T) wg[k] = k < K ? (wgt ? wgt[(int64_t)n * K + k] : 1.f) : 0.f;
+    if (tid <= K) wg[tid] = tid < K ? wv0 : 0.f;
+    for (int k = tid + UL_T; k <= K; k += UL_T) wg[k] = k < K ? (wgt ? wgt[(int64_t)n * K + k] : 1.f) : 0.f;
     for (int c = tid; c <= ncell; c += UL_T) {
         const int xq = first_dst_ge(cell_lo + c, sx, w, W);
         xs[c] = xq;
