@@ -45,10 +45,11 @@ def kernel_bytes(s: EpisodeShape, sF: int):
     N, way, shot, K, C = s.N, s.way, s.shot, s.K, s.c
     B, P, Q, NB = N * way * shot, s.h * s.w, s.H * s.W, N * way
     n_part = (P + 63) // 64
-    if K > 32 and P >= 4:
-        # K > 32: persistent blocks write one dWn slab per GROUP of position tiles (dev_classify.hpp,
-        # cls_bwd_wide_groups): 6 per episode at C3, 15 at C5, instead of 27 / 103
-        tpb = (2 * N * n_part + 255) // 256
+    if P >= 4:
+        # persistent blocks write one dWn slab per GROUP of position tiles (dev_classify.hpp,
+        # cls_bwd_wide_groups): 14 per episode at C2, 6 at C3, 15 at C5, instead of 27 / 27 / 103
+        tgt = 512 if (K <= 32 and 2 * N * n_part >= 1536) else 256
+        tpb = (2 * N * n_part + tgt - 1) // tgt
         n_part = (n_part + tpb - 1) // tpb
     nsl, G = C // 16, N * way
     return {

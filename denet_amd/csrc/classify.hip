@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __rest
     STAMP(0);
     load_chunk(0, bA);                             // in flight under the Wn staging
 
-    constexpr int SUc = RT == 2 ? 16 : RT == 3 ? 24 : 16;
+    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : RT == 3 ? 24 : 16;
     stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
     // rows K .. 32*RT-1 of the LDS image are zeros: the MFMA A operand needs no row mask (a select between the
     // LDS read and the MFMA also re-writes a register the previous MFMA may still be reading)
@@ -802,7 +802,11 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                                int64_t way, int64_t K, int64_t C, int64_t P, int base, float* logits, float* bin,
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
-    if (RT >= 2) {
+    // K <= 32 with many tiles: layout (b) below (a wave per tile, Wn staged once per four tiles) instead of the
+    // latency-oriented eight-waves-per-tile kernel
+    // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
+    const bool wide1 = RT == 1 && N * ((P + CL_TP - 1) / CL_TP) >= 384;
+    if (RT >= 2 || wide1) {
         // K > 32: Wn[n] resident in LDS.  Two layouts: (a) units of (32-position half tile, 32-row tile) dealt to
         // 8 waves, N x groups ~ 256 blocks -- a SIMD carries ceil(units / 4) x 128 MFMAs; (b) a wave per 64-position
         // tile and four tiles per block -- 768 MFMAs per SIMD at RT = 3, but every Fq element loaded once, 8 bytes
@@ -814,7 +818,7 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
         if (groups > nht) groups = nht;
         if (groups < (nht + CLW_MAXH - 1) / CLW_MAXH) groups = (nht + CLW_MAXH - 1) / CLW_MAXH;
         const int64_t units = ((nht + groups - 1) / groups) * RT;
-        const bool by_units = ((units + 3) / 4) * 128 * 3 <= (int64_t)RT * 256 * 2;
+        const bool by_units = !wide1 && ((units + 3) / 4) * 128 * 3 <= (int64_t)RT * 256 * 2;
         if (!by_units) {
             const size_t lds4 = (size_t)32 * RT * (C + 1) * 4;          // rows K .. 32*RT-1 are zero padding
             if (lds4 > 160 * 1024 || RT > 4) return DENET_E_UNSUPPORTED;
@@ -828,6 +832,7 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                            labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
     }
             switch (RT) {
+                case 1: if (C == 64) CL_WIDE4(1, 1) else CL_WIDE4(1, 4) break;
                 case 2: if (C == 64) CL_WIDE4(2, 1) else CL_WIDE4(2, 4) break;
                 case 3: if (C == 64) CL_WIDE4(3, 1) else CL_WIDE4(3, 4) break;
                 default: if (C == 64) CL_WIDE4(4, 1) else CL_WIDE4(4, 4) break;

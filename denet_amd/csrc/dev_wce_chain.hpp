@@ -350,7 +350,11 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
             // moments (1, e, r, r*e) of pixel e = hN + j, 16 bits each
             const unsigned lo = lo0 + ((unsigned)j << 16), hi = hi0 + hi1 * (unsigned)j;
             const int slot = lb < K ? lb * ncmax + cl1 : kcol + item1;
+#ifndef WC_DIAG_NO_ATOMIC
             atomicAdd(&oh[slot], ((unsigned long long)hi << 32) | lo);
+#else
+            if (slot == 0x7fffffff) oh[0] = ((unsigned long long)hi << 32) | lo;
+#endif
             if (GRAD) {
                 const float s = wy * __builtin_amdgcn_rcpf(sv);
                 reinterpret_cast<float*>(srow + j)[rodd] = s;

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
 
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
-                          float* losses, int n_part, int N, hipStream_t st) {
-    if (RT >= 2 && g.P >= 4) {          // persistent blocks (quad loads need P >= 4; see cls_bwd_parts below)
+                          float* losses, int n_part, int N, bool wide, hipStream_t st) {
+    if (wide) {                         // persistent blocks (quad loads need P >= 4; see cls_bwd_parts below)
         const size_t ldw = CLW_BWD_LDS(RT);
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT>), ldw))
             return DENET_E_LAUNCH;
@@ -316,7 +316,11 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
     if (P * 4 > 64 * 1024 || B * ((C + 15) / 16) > (int64_t)1 << 30) return DENET_E_UNSUPPORTED;
     const int RT = (int)((K + 31) / 32);
     // dWn slabs per episode: one per position tile, or (K > 32, persistent blocks) one per tile group
-    const int n_part = (RT >= 2 && P >= 4) ? cls_bwd_wide_groups(N, P) : (int)denet_classify_bwd_parts(P);
+    // persistent blocks at every K (quad loads need P >= 4).  K <= 32 against one tile per block: C2 step
+    // 88.2 vs 89.7 us at 8 episodes (14 slabs per episode instead of 27 for B2 to sum), 1.000 vs 1.024 ms at 128
+    // (B2 18 vs 57 us)
+    const bool wide = P >= 4;
+    const int n_part = wide ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
     const bool f32 = feat_dtype == DENET_F32;
     hipStream_t st = (hipStream_t)stream;
     DropGen gd, wd;
@@ -334,9 +338,9 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
         const float* pp_ptr = have_focal ? s.part_p : nullptr;
         int rc = f32 ? RT_DISPATCH(launch_bwd_dwn, float, RT, g, g2, pp_ptr, (int)NB, (int)pp, losses, n_part, (int)N,
-                                   st)
+                                   wide, st)
                      : RT_DISPATCH(launch_bwd_dwn, unsigned short, RT, g, g2, pp_ptr, (int)NB, (int)pp, losses,
-                                   n_part, (int)N, st);
+                                   n_part, (int)N, wide, st);
         if (rc) return rc;
         DENET_CHECK_LAUNCH();
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;

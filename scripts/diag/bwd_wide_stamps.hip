@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsB
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 20, K = argc > 2 ? atoi(argv[2]) : 81, P = argc > 3 ? atoi(argv[3]) : 1681, C = 256;
     const int only = argc > 4 ? atoi(argv[4]) : 0;     // 1: launch only the stamped role's blocks
-    const int ngrp = cls_bwd_wide_groups(N, P);
+    const int ngrp = cls_bwd_wide_groups(N, P, RT);
     float *Fq, *dFq, *Wn, *da, *db, *slab;
     CK(hipMalloc(&Fq, (size_t)N * C * P * 4)); CK(hipMalloc(&dFq, (size_t)N * C * P * 4)); CK(hipMalloc(&Wn, (size_t)N * K * C * 4));
     CK(hipMalloc(&da, (size_t)N * K * P * 4)); CK(hipMalloc(&db, (size_t)N * K * P * 4)); CK(hipMalloc(&slab, (size_t)N * ngrp * K * C * 4));
