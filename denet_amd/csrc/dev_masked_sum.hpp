@@ -8,22 +8,39 @@
 // ---------------------------------------------------------------------------
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
-    static constexpr int N = 4;
+    static constexpr int N = 4, LOG = 2;
     typedef f32x4 type;
-    static __device__ __forceinline__ float dot(const type& v, const float* m) {
-        return v[0] * m[0] + v[1] * m[1] + v[2] * m[2] + v[3] * m[3];
-    }
+    static __device__ __forceinline__ float elem(const type& v, int e) { return v[e]; }
 };
 template <> struct Vec16<unsigned short> {
-    static constexpr int N = 8;
+    static constexpr int N = 8, LOG = 3;
     typedef u16x8 type;
-    static __device__ __forceinline__ float dot(const type& v, const float* m) {
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a += bf16_to_f32(v[e]) * m[e];
-        return a;
-    }
+    static __device__ __forceinline__ float elem(const type& v, int e) { return bf16_to_f32(v[e]); }
 };
+
+// LDS image of a mask row for the two streaming kernels: V planes (V = elements per 16-byte vector), plane q
+// holds mask[q], mask[q + V], ...  Lane i of a wave reads element e of ITS vector, mask[head + V i + e], at
+// plane[(head + e) % V][(head + e) / V + i]: consecutive lanes, consecutive banks, one address register per
+// plane and the vector index as an immediate offset.  (With the row stored as [P] floats the lanes sit 4 V
+// bytes apart: 8-way bank conflicts at V = 4, 16-way at V = 8 -- the bf16 pooling stream ran LDS-bound at
+// 3.2 TB/s against 6.0 for fp32 over the same bytes, scripts/diag/pool_stamps.)  The image is followed by a
+// tail of MASK_TAIL floats: vectors past the end of a row are read unclamped and discarded by a select.
+#define MASK_TAIL 1024
+// bf16 always uses the planar image.  fp32 (8-way conflicts, four reads per vector) uses it where it measured
+// faster -- the short-row pooling kernel (C2 F1 18.8 -> 17.9 us, C3 85.1 -> 83.9) and the flat dFs writer (C3 B3
+// 84.9 -> 83.2 us) -- and keeps the row as [P] floats in the long-row pooling kernel (the planar addressing costs
+// it 47 registers: 6.0 -> 5.2 TB/s at 81 x 81) and in the row-per-wave dFs writer (C2 B3 16.6 vs 16.95 us).
+// FAST = !LONG for the pooling kernel, NT for the dFs writer.
+#ifndef DENET_POOL_PLANAR_F32
+#define DENET_POOL_PLANAR_F32 0
+#endif
+template <typename T, bool FAST> struct MaskImage;
+template <bool FAST> struct MaskImage<float, FAST> { static constexpr bool PLANAR = FAST || DENET_POOL_PLANAR_F32; };
+template <bool FAST> struct MaskImage<unsigned short, FAST> { static constexpr bool PLANAR = true; };
+template <int V> __host__ __device__ __forceinline__ int mask_plane_stride(int P) { return ((P + V - 1) / V + 2) | 1; }
+template <int V, bool PLANAR> __host__ __device__ __forceinline__ int mask_image_floats(int P) {
+    return (PLANAR ? V * mask_plane_stride<V>(P) : ((P + 3) & ~3)) + MASK_TAIL;
+}
 
 // Body of K1 for block (cblk, b): `sm` [P] floats of LDS.  With Ys != nullptr the mask is gathered
 // here from the int64 label map (K0 fused: nearest resize, model/common.py:189-190) and the block
@@ -43,13 +60,17 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
     // Sliced chain, first mat-vec (gate layer 1, model/common.py:226) as a split-K partial: this block
     // owns att[c0..c0+16) of image b, so it can form  pre1_part[b][cblk][o] = sum_r W1[o][c0+r] * att[c0+r]
     // for every output row o.  rows_per_block is 16 here.
-    float* sl = sm + ((P + 3) & ~3) + 4;                   // [16] this block's att = S / (h*w)
+    constexpr int V = Vec16<T>::N, LV = Vec16<T>::LOG;
+    constexpr bool PLANAR = MaskImage<T, !LONG>::PLANAR;
+    const int PS = mask_plane_stride<V>(P), MP = mask_image_floats<V, PLANAR>(P);
+    auto midx = [&](int p) { return PLANAR ? (p & (V - 1)) * PS + (p >> LV) : p; };
+    float* sl = sm + MP + 4;                               // [16] this block's att = S / (h*w)
     const int wq = threadIdx.x & 3, wog = threadIdx.x >> 2;
     // W1 slice: four lanes share a row (16 B each, 64 B per row), four loads cover rows og, og+64,
     // og+128, og+192.  It is requested behind the LAST round of feature loads (with the first round it
     // delays the stream: 21.0 vs 20.3 us at C2 batch 8) and waits in LDS, each thread parking and
     // re-reading its own 64 bytes.
-    float* wsl = sm + ((P + 3) & ~3) + 4 + 16 + (int)threadIdx.x * 16;
+    float* wsl = sm + MP + 4 + 16 + (int)threadIdx.x * 16;
     auto fetch_w1 = [&]() {
         if (W1 == nullptr) return;
 #pragma unroll
@@ -57,7 +78,6 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             *reinterpret_cast<f32x4*>(wsl + 4 * m) =
                 *reinterpret_cast<const f32x4*>(W1 + (int64_t)min(wog + 64 * m, C - 1) * C + c0 + 4 * wq);
     };
-    constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
     constexpr int NR = 2;                                 // rows of a wave in flight together (more costs occupancy)
@@ -88,19 +108,31 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             for (int u = 0; u < NV; ++u) v[q][u] = rv[min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0)];
         }
     };
+    // mask[head + V i + e] for vector i = lane + (immediate): one LDS address per plane (row-major: one in all)
+    auto plane_bases = [&](int head, const float* (&pb)[V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) pb[e] = PLANAR ? sm + midx(head + e) + lane : sm + head + lane * V + e;
+    };
+    auto dotp = [&](const vec_t& x, const float* const (&pb)[V], int off) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < V; ++e) a += Vec16<T>::elem(x, e) * pb[e][PLANAR ? off : off * V];
+        return a;
+    };
     auto consume = [&](int r0) {
         float accs[NR];
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int head = heads[q], nvec = nvecs[q], t0 = head + nvec * V;
-            float acc = (lane < head) ? hv[q] * sm[min(lane, P - 1)] : 0.f;
+            float acc = (lane < head) ? hv[q] * sm[midx(min(lane, P - 1))] : 0.f;
+            const float* pb[V];
+            plane_bases(head, pb);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                const int i = lane + 64 * u;
-                const float d = Vec16<T>::dot(v[q][u], sm + head + min(i, nvec > 0 ? nvec - 1 : 0) * V);
-                acc += (i < nvec) ? d : 0.f;
+                const float d = dotp(v[q][u], pb, 64 * u);          // (past the row's end: tail words, discarded)
+                acc += (lane + 64 * u < nvec) ? d : 0.f;
             }
-            acc += (t0 + lane < P) ? tv[q] * sm[min(t0 + lane, P - 1)] : 0.f;
+            acc += (t0 + lane < P) ? tv[q] * sm[midx(min(t0 + lane, P - 1))] : 0.f;
             accs[q] = wave_sum(acc);
         }
 #pragma unroll
@@ -146,21 +178,21 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         for (int p = threadIdx.x; p < P; p += 256) {
             const int y = p / w, x = p - y * w;
             const float m = (float)src[(int64_t)nearest_src(y, sy, H) * W + nearest_src(x, sx, W)];
-            sm[p] = m;
+            sm[midx(p)] = m;
             acc += m;
             if (cblk == 0) mrow[p] = m;
         }
         if (cblk == 0) {
             // every partial sum is a small integer: exact in any order
             acc = wave_sum(acc);
-            float* red = sm + ((P + 3) & ~3);
+            float* red = sm + MP;
             if (lane == 0) red[wave] = acc;
             __syncthreads();
             if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
         }
     } else {
 #pragma unroll 8
-        for (int p = threadIdx.x; p < P; p += 256) sm[p] = mrow[p];
+        for (int p = threadIdx.x; p < P; p += 256) sm[midx(p)] = mrow[p];
     }
     __syncthreads();
 
@@ -186,7 +218,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         int head = mis ? V - mis : 0;
         if (head > P) head = P;
         const float hv1 = FeatIO<T>::load(row + min(lane, P - 1));
-        float acc = (lane < head) ? hv1 * sm[min(lane, P - 1)] : 0.f;
+        float acc = (lane < head) ? hv1 * sm[midx(min(lane, P - 1))] : 0.f;
         const int nvec = (P - head) / V;
         const vec_t* rv = reinterpret_cast<const vec_t*>(row + head);
         const int t0 = head + nvec * V;
@@ -199,22 +231,26 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
 #pragma unroll
             for (int u = 0; u < NV; ++u) vv[u] = rv[max(min(i0 + 64 * u, nvec - 1), 0)];
         };
-        auto eat = [&](int i0, const vec_t (&vv)[NV]) {
+        const float* pb[V];
+        plane_bases(head, pb);
+        // (i up to nvec + 959 is read: the image's tail; the select discards it)
+        auto eat = [&](int i0, int off, const vec_t (&vv)[NV]) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                const int i = i0 + 64 * u;
-                const float d = Vec16<T>::dot(vv[u], sm + head + max(min(i, nvec - 1), 0) * V);
-                acc += (i < nvec) ? d : 0.f;
+                const float d = dotp(vv[u], pb, off + 64 * u);
+                acc += (i0 + off + 64 * u < nvec) ? d : 0.f;
             }
         };
         fetch(lane, va);
         for (int i0 = lane; i0 < nvec; i0 += 2 * 64 * NV) {
             fetch(i0 + 64 * NV, vb);
-            eat(i0, va);
+            eat(i0, 0, va);
             fetch(i0 + 2 * 64 * NV, va);
-            eat(i0 + 64 * NV, vb);
+            eat(i0, 64 * NV, vb);
+#pragma unroll
+            for (int e = 0; e < V; ++e) pb[e] += (PLANAR ? 1 : V) * 2 * 64 * NV;
         }
-        acc += (t0 + lane < P) ? tv1 * sm[min(t0 + lane, P - 1)] : 0.f;
+        acc += (t0 + lane < P) ? tv1 * sm[midx(min(t0 + lane, P - 1))] : 0.f;
         acc = wave_sum(acc);
         if (lane == 0) {
             S[(int64_t)b * C + c] = acc;
@@ -228,7 +264,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
 // (short rows, fp32: 134 VGPRs, 3 waves per SIMD; forcing 4 with amdgpu_waves_per_eu spills 7 registers and the
 // stream runs 10 % slower at every batch size: more resident blocks do not buy bandwidth)
 template <typename T, bool LONG>
-__global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
                                                             const int64_t* __restrict__ Ys,
                                                             float* __restrict__ mask, float* __restrict__ cnt,
                                                             float* __restrict__ S, int C, int P,
@@ -282,7 +318,12 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     const int c0 = cblk * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* mrow = mask + (int64_t)b * P;
-    float* red = sm + ((P + 3) & ~3);        // [4][16]
+    // the mask row in LDS: same image as the pooling kernel's (planar for bf16, MaskImage)
+    constexpr int V = Vec16<T>::N, LV = Vec16<T>::LOG;
+    constexpr bool PLANAR = MaskImage<T, NT>::PLANAR;
+    const int PS = mask_plane_stride<V>(P), MP = mask_image_floats<V, PLANAR>(P);
+    auto midx = [&](int p) { return PLANAR ? (p & (V - 1)) * PS + (p >> LV) : p; };
+    float* red = sm + MP;                    // [4][16]
     float* coefs = red + 64;                 // [16]
     constexpr bool SLICED = NSLT > 0;
     // every global load of the block is requested before the first wait: the coef operands and the
@@ -321,8 +362,8 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-        if ((int)threadIdx.x + 256 * u < P) sm[threadIdx.x + 256 * u] = mv[u];
-    for (int p = threadIdx.x + 2048; p < P; p += 256) sm[p] = mrow[p];
+        if ((int)threadIdx.x + 256 * u < P) sm[midx(threadIdx.x + 256 * u)] = mv[u];
+    for (int p = threadIdx.x + 2048; p < P; p += 256) sm[midx(p)] = mrow[p];
     if constexpr (SLICED) {
         __syncthreads();
         if (threadIdx.x < 16) {
@@ -335,7 +376,6 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     }
     __syncthreads();
 
-    constexpr int V = Vec16<T>::N;
     typedef typename Vec16<T>::type vec_t;
     if constexpr (!NT) {
         // streams the last-level cache absorbs (C2, C5): one wave per channel row, four rows of a block in flight
@@ -348,23 +388,26 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
             const int mis = (int)(((uintptr_t)row / sizeof(T)) % V);
             int head = mis ? V - mis : 0;
             if (head > P) head = P;
-            if (lane < head) FeatIO<T>::store(row + lane, k * sm[lane]);
+            if (lane < head) FeatIO<T>::store(row + lane, k * sm[midx(lane)]);
             const int nvec = (P - head) / V;
             vec_t* rv = reinterpret_cast<vec_t*>(row + head);
+            // mask[head + V i + e]: one LDS address per plane, the trip as an immediate offset (row-major: one in all)
+            const float* pb[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) pb[e] = PLANAR ? sm + midx(head + e) : sm + head + e;
 #pragma unroll 4
             for (int i = lane; i < nvec; i += 64) {
-                const float* m = sm + head + i * V;
                 vec_t v;
-                if constexpr (V == 4) {
-                    v[0] = k * m[0]; v[1] = k * m[1]; v[2] = k * m[2]; v[3] = k * m[3];
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = f32_to_bf16(k * m[e]);
+                for (int e = 0; e < V; ++e) {
+                    const float x = k * pb[e][PLANAR ? i : i * V];
+                    if constexpr (V == 4) v[e] = x;
+                    else v[e] = f32_to_bf16(x);
                 }
                 rv[i] = v;
             }
             const int t0 = head + nvec * V;
-            if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[t0 + lane]);
+            if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[midx(t0 + lane)]);
         }
     } else {
         // The block's 16 channel rows are ONE contiguous span of rows * P elements (NCHW): all 256 threads write it
@@ -378,7 +421,7 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
         auto value = [&](int e) {
             int p;
             const int r = wc_divmod_p(e, P, invP, p);
-            return coefs[r] * sm[p];
+            return coefs[r] * sm[midx(p)];
         };
         const int mis = (int)(((uintptr_t)out / sizeof(T)) % V);
         int head = mis ? V - mis : 0;
@@ -398,7 +441,7 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
             if (p0 + V <= P) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const float x = k0 * sm[p0 + e];
+                    const float x = k0 * sm[midx(p0 + e)];
                     if constexpr (V == 4) v[e] = x;
                     else v[e] = f32_to_bf16(x);
                 }
@@ -407,7 +450,7 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const bool wrap = p0 + e >= P;
-                    const float x = (wrap ? k1 : k0) * sm[wrap ? p0 + e - P : p0 + e];
+                    const float x = (wrap ? k1 : k0) * sm[midx(wrap ? p0 + e - P : p0 + e)];
                     if constexpr (V == 4) v[e] = x;
                     else v[e] = f32_to_bf16(x);
                 }

@@ -366,21 +366,29 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         const int gx = only_dfs ? 0 : (int)C / WG_ROWS;      // blocks of each of the roles dW1, dW2, dWl
         const int rpb = 16, ncb = (int)(C / 16);
         const int64_t ndfs = no_dfs ? 0 : B * ncb;
-        size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;
-        if (lds < 4096) lds = 4096;
         dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
         // dFs streams that do not fit the 256 MB last-level cache go around it (dev_masked_sum.hpp, NT);
         // measured break-even between C5 (269 MB of bf16: cached stores win) and C3 (344 MB of fp32: NT wins)
         const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)320 << 20);
+        // LDS: the mask image of the dFs blocks (dev_masked_sum.hpp) + their 64 + 16 floats
+        size_t lds = (size_t)((f32 ? (nt ? mask_image_floats<4, MaskImage<float, true>::PLANAR>((int)P)
+                                         : mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P))
+                                   : mask_image_floats<8, true>((int)P)) + 64 + 16) * 4;
+        if (lds < 4096) lds = 4096;
 #define TAIL_GO(TT, NSLT)                                                                                           \
-    if (nt)                                                                                                         \
+    if (nt) {                                                                                                       \
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, true>), lds))     \
+            return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, true>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs,  \
                            (int)C, (int)P, rpb, ncb, gx);                                                           \
-    else                                                                                                            \
+    } else {                                                                                                        \
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, false>), lds))    \
+            return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, false>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, \
-                           (int)C, (int)P, rpb, ncb, gx)
+                           (int)C, (int)P, rpb, ncb, gx);                                                           \
+    }
         if (f32) {
             if (C == 256) { TAIL_GO(float, 16); } else { TAIL_GO(float, 4); }
         } else {

@@ -58,20 +58,28 @@ extern "C" int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_
 static inline int pick_rows_per_block(int64_t C) { return C >= DENET_RPB ? DENET_RPB : (int)C; }
 
 // the pooling kernel: short rows (up to 512 16-byte vectors: whole rows in flight) or long rows (rolling loop)
-static void launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float* mask, float* cnt, float* S, int C, int P,
-                        int rpb, int H, int W, int h, int w, const float* W1, float* pre1_part, dim3 grid, size_t lds,
-                        hipStream_t st) {
+static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float* mask, float* cnt, float* S, int C, int P,
+                       int rpb, int H, int W, int h, int w, const float* W1, float* pre1_part, dim3 grid, hipStream_t st) {
     const bool f32 = feat_dtype == DENET_F32;
     const bool longr = P / (f32 ? 4 : 8) > 512;
+    // LDS: the planar mask image (dev_masked_sum.hpp) + 4 + 16 floats (+ the parked W1 slices)
+    const size_t lds = (size_t)((f32 ? (longr ? mask_image_floats<4, MaskImage<float, false>::PLANAR>(P)
+                                          : mask_image_floats<4, MaskImage<float, true>::PLANAR>(P))
+                                   : mask_image_floats<8, true>(P)) + 4 + 16) * 4 + (W1 ? 256 * 64 : 0);
 #define POOL_GO(TT, LG)                                                                                           \
-    hipLaunchKernelGGL((masked_sum_fwd_kernel<TT, LG>), grid, dim3(256), lds, st, (const TT*)Fs, Ys, mask, cnt, S, C, P, \
-                       rpb, H, W, h, w, W1, pre1_part)
+    do {                                                                                                          \
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_fwd_kernel<TT, LG>), lds))          \
+            return DENET_E_LAUNCH;                                                                                \
+        hipLaunchKernelGGL((masked_sum_fwd_kernel<TT, LG>), grid, dim3(256), lds, st, (const TT*)Fs, Ys, mask, cnt, S, C, \
+                           P, rpb, H, W, h, w, W1, pre1_part);                                                    \
+    } while (0)
     if (f32) {
         if (longr) POOL_GO(float, true); else POOL_GO(float, false);
     } else {
         if (longr) POOL_GO(unsigned short, true); else POOL_GO(unsigned short, false);
     }
 #undef POOL_GO
+    return DENET_OK;
 }
 
 extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float* mask, int64_t B, int64_t C,
@@ -81,10 +89,10 @@ extern "C" int denet_masked_sum_fwd(const void* Fs, int feat_dtype, const float*
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
-    size_t lds = (size_t)P * 4 + 32 + 64;
     if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
-    launch_pool(Fs, feat_dtype, nullptr, (float*)mask, nullptr, S, (int)C, (int)P, rpb, 0, 0, 0, 0, nullptr, nullptr, grid, lds,
-                (hipStream_t)stream);
+    if (int rc = launch_pool(Fs, feat_dtype, nullptr, (float*)mask, nullptr, S, (int)C, (int)P, rpb, 0, 0, 0, 0, nullptr,
+                             nullptr, grid, (hipStream_t)stream))
+        return rc;
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -96,15 +104,21 @@ extern "C" int denet_masked_sum_bwd(const float* mask, const float* coef, int64_
     if (P * 4 > 64 * 1024 || B > 65535) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)((C + rpb - 1) / rpb), (unsigned)B);
-    size_t lds = (size_t)((P + 3) & ~(int64_t)3) * 4 + (64 + 16) * 4;     // mask row + the block's 16 coefficients
-    if (feat_dtype == DENET_F32)
+    // mask image (dev_masked_sum.hpp) + 64 floats + the block's 16 coefficients
+    if (feat_dtype == DENET_F32) {
+        const size_t lds = (size_t)(mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P) + 64 + 16) * 4;
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_bwd_kernel<float>), lds)) return DENET_E_LAUNCH;
         hipLaunchKernelGGL(masked_sum_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, mask, coef,
                            (float*)dFs, (int)C, (int)P, rpb);
-    else if (feat_dtype == DENET_BF16)
+    } else if (feat_dtype == DENET_BF16) {
+        const size_t lds = (size_t)(mask_image_floats<8, true>((int)P) + 64 + 16) * 4;
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_bwd_kernel<unsigned short>), lds))
+            return DENET_E_LAUNCH;
         hipLaunchKernelGGL(masked_sum_bwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream, mask,
                            coef, (unsigned short*)dFs, (int)C, (int)P, rpb);
-    else
+    } else {
         return DENET_E_UNSUPPORTED;
+    }
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -126,7 +140,6 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     if (W1 && ((C & 15) || C > 256)) return DENET_E_UNSUPPORTED;
     const int rpb = pick_rows_per_block(C);
     dim3 grid((unsigned)(((C + rpb - 1) / rpb) * B));
-    size_t lds = (size_t)P * 4 + 32 + 64 + (W1 ? 256 * 64 : 0);
     // The in-kernel gather touches one 64-byte sector of the label map per mask element, once per channel
     // block: C/16 times 64 P bytes per image against C P sF bytes of features.  At 41 x 41 that is cheaper
     // than a launch of its own; from P = 4096 on (81 x 81: 420 KB of sectors per block against 210 KB of bf16
@@ -140,8 +153,9 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
         Ys = nullptr;
     }
     if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
-    launch_pool(Fs, feat_dtype, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w, W1, pre1_part, grid,
-                lds, (hipStream_t)stream);
+    if (int rc = launch_pool(Fs, feat_dtype, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w, W1,
+                             pre1_part, grid, (hipStream_t)stream))
+        return rc;
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }

@@ -9,9 +9,13 @@ int denet_ensure_dynamic_lds(const void* kernel, size_t bytes) {
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 40, C = 256, h = 41, w = 41, H = 321, W = 321, P = h * w;
+    // usage: pool_stamps [B=40] [chain=1] [bin us=1] [h=41] [H=321] [bf16=0]
+    const int B = argc > 1 ? atoi(argv[1]) : 40, C = 256, h = argc > 4 ? atoi(argv[4]) : 41, w = h,
+              H = argc > 5 ? atoi(argv[5]) : 321, W = H, P = h * w;
     const int chain = argc > 2 ? atoi(argv[2]) : 1;
     const double binw = argc > 3 ? atof(argv[3]) : 1.0;   // histogram bin width, us
+    const int bf16 = argc > 6 ? atoi(argv[6]) : 0;
+    const int fdt = bf16 ? DENET_BF16 : DENET_F32;
     float *Fs, *mask, *cnt, *S, *W1, *pre1;
     int64_t* Ys;
     CK(hipMalloc(&Fs, (size_t)B * C * P * 4)); CK(hipMemset(Fs, 0, (size_t)B * C * P * 4));
@@ -29,12 +33,12 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0));
         // chain: 1 = fused mask gather + split-K tail (the fused step's launch), 0 = gather, no tail,
         //        2 = mask resized beforehand, pooling only (denet_masked_sum_fwd)
-        int rc = chain == 2 ? denet_masked_sum_fwd(Fs, DENET_F32, mask, B, C, h * w, S, nullptr)
-                            : denet_masked_pool_fwd_chain(Fs, DENET_F32, Ys, B, C, H, W, h, w, mask, cnt, S, chain ? W1 : nullptr, chain ? pre1 : nullptr, nullptr);
+        int rc = chain == 2 ? denet_masked_sum_fwd(Fs, fdt, mask, B, C, h * w, S, nullptr)
+                            : denet_masked_pool_fwd_chain(Fs, fdt, Ys, B, C, H, W, h, w, mask, cnt, S, chain ? W1 : nullptr, chain ? pre1 : nullptr, nullptr);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("pool B=%d chain=%d rc=%d total %.1f us\n", B, chain, rc, ms * 1e3);
+        printf("pool B=%d %dx%d %s chain=%d rc=%d total %.1f us = %.2f TB/s\n", B, h, w, bf16 ? "bf16" : "f32", chain, rc, ms * 1e3, (double)B * C * P * (bf16 ? 2 : 4) / (ms * 1e-3) / 1e12);
         if (rep == 3) {
             std::vector<unsigned long long> bs(nblk * 3); CK(hipMemcpy(bs.data(), d_bs, nblk * 24, hipMemcpyDeviceToHost));
             unsigned long long t0 = ~0ull;
