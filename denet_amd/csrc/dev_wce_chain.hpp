@@ -91,15 +91,20 @@ __device__ __forceinline__ ChainY wc_chain_exponents(const float* raw0, const fl
     return p;
 }
 
+// s (weight / sum-exp) of a cell row pair: EM pixel slots of 8 bytes, padded to a cell stride of 4 m + 2 slots --
+// phase 2 reads it with ds_read_b128, lanes = consecutive cells: at 8 slots (64 B) a 16-lane group falls on four
+// of the sixteen 16-byte bank slots (3.5-way conflicts, 10.9 M of the kernel's 20.2 M LDS cycles at C3, PMC
+// SQ_LDS_BANK_CONFLICT), at 10 slots (80 B) every cell of a group has a slot of its own
+__host__ __device__ constexpr int wc_cell_stride(int EM) { return (((EM + 1) & ~1) % 4 == 0) ? ((EM + 1) & ~1) + 2 : ((EM + 1) & ~1); }
 // LDS floats of the chain path (host and device must agree); KC = classes per table chunk (even, or K)
 __host__ __device__ __forceinline__ int wc_lds_floats(int K, int ncmax, int rows_max, int KC, int EM, bool grad) {
-    const int kcol = K * ncmax, EMP2 = (EM + 1) & ~1, KC2 = (KC + 1) >> 1, RP = (rows_max + 1) >> 1;
+    const int kcol = K * ncmax, CS = wc_cell_stride(EM), KC2 = (KC + 1) >> 1, RP = (rows_max + 1) >> 1;
     int off = 2 * kcol + 2 * ncmax + (K + 1) + 16 + ncmax + (ncmax + 1) + 1;
     off = (off + 3) & ~3;
     const int tsz = 4 * rows_max * KC2 * ncmax, asz = grad ? 4 * kcol : 0;
     off += tsz > asz ? tsz : asz;
     off = (off + 3) & ~3;
-    off += grad ? 2 * RP * ncmax * EMP2 : 0;
+    off += grad ? 2 * RP * ncmax * CS : 0;
     off = (off + 3) & ~3;
     off += 2 * (kcol + UL_T / 2);
     return off;
@@ -109,7 +114,8 @@ __host__ __device__ __forceinline__ int wc_lds_floats(int K, int ncmax, int rows
 // EM: label columns per cell (the widest cell of the geometry: 8 at 41 -> 321, 9 at 81 -> 642).
 template <bool GRAD, int EM, int RSF>
 __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx, float* sm) {
-    constexpr int EMP2 = (EM + 1) & ~1;                   // s row stride in pixel slots (16-byte reads of 2 pixels)
+    constexpr int EMP2 = (EM + 1) & ~1;                   // pixel slots read per cell row pair (16-byte reads of 2 pixels)
+    constexpr int CS = wc_cell_stride(EM);                // cell stride of s in pixel slots (bank-conflict padding)
     const float* __restrict__ logits = g.logits;
     const int64_t* __restrict__ Y = g.Y;
     const float* __restrict__ wgt = g.wgt;
@@ -144,8 +150,8 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
         off += tsz > asz ? tsz : asz;
         off = (off + 3) & ~3;
     }
-    f32x2* sbuf = reinterpret_cast<f32x2*>(sm + off);     // GRAD: [RP][ncmax][EMP2] weight / sum-exp of rows (2i, 2i+1)
-    off += GRAD ? 2 * RP * ncmax * EMP2 : 0;
+    f32x2* sbuf = reinterpret_cast<f32x2*>(sm + off);     // GRAD: [RP][ncmax][CS] weight / sum-exp of rows (2i, 2i+1)
+    off += GRAD ? 2 * RP * ncmax * CS : 0;
     off = (off + 3) & ~3;
     // label moments [K][ncmax], then one dummy slot per phase-1 item (ignored / padding pixels add there)
     unsigned long long* oh = reinterpret_cast<unsigned long long*>(sm + off);
@@ -183,7 +189,7 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
     for (int i = tid; i < kcol; i += UL_T) oh[i] = 0ull;
     if (GRAD) {
         const f32x2 z2 = {0.f, 0.f};
-        for (int i = tid; i < RP * ncmax * EMP2; i += UL_T) sbuf[i] = z2;
+        for (int i = tid; i < RP * ncmax * CS; i += UL_T) sbuf[i] = z2;
     }
     __syncthreads();
 
@@ -334,7 +340,7 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
             se[e] = se2[e][0] + se2[e][1];
             se[e] += dpp_f32<0xB1>(se[e]);                // the other half of the class pairs
         }
-        f32x2* srow = sbuf + ((r1 >> 1) * ncmax + cl1) * EMP2 + half * NPX;
+        f32x2* srow = sbuf + ((r1 >> 1) * ncmax + cl1) * CS + half * NPX;
         const int rodd = r1 & 1;
         const unsigned hN = (unsigned)(half * NPX);
         const unsigned lo0 = 1u | (hN << 16), hi0 = (((unsigned)r1 * hN) << 16) | (unsigned)r1, hi1 = (unsigned)r1 << 16;
@@ -396,12 +402,12 @@ __device__ __forceinline__ void wce_chain_body(const LossArgs& g, int n, int bx,
         f32x2 E0 = {e00, e00 * sg}, rho = {r00, r00 * ta};      // rows (2j, 2j+1)
         const f32x2 sg2 = {sg * sg, sg * sg}, ta2 = {ta * ta, ta * ta};
         f32x2 A = {0.f, 0.f}, PA = A, B = A, PB = A;
-        const f32x2* srow = sbuf + cl * EMP2;
+        const f32x2* srow = sbuf + cl * CS;
         for (int j = 0; j < npair; ++j) {
             f32x2 s[EMP2];
 #pragma unroll
             for (int q = 0; q < EMP2 / 2; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(srow + j * ncmax * EMP2 + 2 * q);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(srow + j * ncmax * CS + 2 * q);
                 s[2 * q] = {v[0], v[1]};
                 s[2 * q + 1] = {v[2], v[3]};
             }
