@@ -11,27 +11,47 @@
 // K0: mask[b,p] = float(Ys[b, sy, sx]), cnt[b] = sum_p mask[b,p]
 // reference: model/common.py:189-190, 237-238 (F.interpolate nearest)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mask_resize_kernel(const int64_t* __restrict__ Ys, int H, int W,
-                                                          int h, int w, float* __restrict__ mask,
-                                                          float* __restrict__ cnt) {
+// One block of 1024 threads per image; every thread requests its GB elements (clamped, unconditional) before it
+// uses the first: as a loop of 256 threads over the row the kernel paid one memory round trip per 256 elements
+// (seven in a row at 41 x 41, five unrolled trips at 81 x 81: 14 us for 80 images at C5).
+#define MR_T 1024
+template <int GB>
+__global__ __launch_bounds__(MR_T) void mask_resize_kernel(const int64_t* __restrict__ Ys, int H, int W, int h, int w,
+                                                           float* __restrict__ mask, float* __restrict__ cnt) {
     const int b = blockIdx.x;
     const int P = h * w;
     const float sy = nearest_scale(H, h), sx = nearest_scale(W, w);
     const int64_t* src = Ys + (int64_t)b * H * W;
     float acc = 0.f;
-#pragma unroll 8
-    for (int p = threadIdx.x; p < P; p += 256) {
-        int y = p / w, x = p - y * w;
-        int yy = nearest_src(y, sy, H), xx = nearest_src(x, sx, W);
-        float m = (float)src[(int64_t)yy * W + xx];
-        mask[(int64_t)b * P + p] = m;
-        acc += m;
+    for (int p0 = 0; p0 < P; p0 += MR_T * GB) {
+        int64_t lv[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = min(p0 + (int)threadIdx.x + MR_T * u, P - 1);
+            const int y = p / w, x = p - y * w;
+            lv[u] = src[(int64_t)nearest_src(y, sy, H) * W + nearest_src(x, sx, W)];
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int p = p0 + (int)threadIdx.x + MR_T * u;
+            if (p < P) {
+                const float m = (float)lv[u];
+                mask[(int64_t)b * P + p] = m;
+                acc += m;
+            }
+        }
     }
-    __shared__ float red[4];
+    // every partial sum is a small integer: exact in any order
+    __shared__ float red[MR_T / 64];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR_T / 64; ++i) t += red[i];
+        cnt[b] = t;
+    }
 }
 
 #include "dev_masked_sum.hpp"
@@ -46,8 +66,12 @@ extern "C" int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_
     if (!Ys || !mask || !cnt) return DENET_E_BADARG;
     if (!fits_int(B) || !fits_int(H) || !fits_int(W) || !fits_int(h) || !fits_int(w) || !fits_int(h * w))
         return DENET_E_BADARG;
-    hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, Ys, (int)H,
-                       (int)W, (int)h, (int)w, mask, cnt);
+    if (h * w <= 2 * MR_T)
+        hipLaunchKernelGGL(mask_resize_kernel<2>, dim3((unsigned)B), dim3(MR_T), 0, (hipStream_t)stream, Ys, (int)H,
+                           (int)W, (int)h, (int)w, mask, cnt);
+    else
+        hipLaunchKernelGGL(mask_resize_kernel<8>, dim3((unsigned)B), dim3(MR_T), 0, (hipStream_t)stream, Ys, (int)H,
+                           (int)W, (int)h, (int)w, mask, cnt);
     DENET_CHECK_LAUNCH();
     return DENET_OK;
 }
@@ -144,10 +168,11 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     // block: C/16 times 64 P bytes per image against C P sF bytes of features.  At 41 x 41 that is cheaper
     // than a launch of its own; from P = 4096 on (81 x 81: 420 KB of sectors per block against 210 KB of bf16
     // features) the mask is resized once per image first and the blocks read it back as P floats.  The same
-    // from 128 images on: the gather is 1681 scattered 8-byte loads per block, sixteen times per image, and
+    // from 64 images on: the gather is 1681 scattered 8-byte loads per block, sixteen times per image, and
     // costs the stream 15 us of 86 at 200 images (C3) and 40 of 258 at 640 (scripts/diag/pool_stamps: modes
-    // 1 / 0 / 2); the extra launch costs ~4 us, which only small batches cannot afford.
-    if (P >= 4096 || B >= 128) {
+    // 1 / 0 / 2); the extra launch costs ~4 us, which only small batches cannot afford (C2 step: 88.7 vs 87.2 us
+    // at 40 images, 160.5 vs 161.7 us at 80).
+    if (P >= 4096 || B >= 64) {
         int rc = denet_mask_resize(Ys, B, H, W, h, w, mask, cnt, stream);
         if (rc) return rc;
         Ys = nullptr;
