@@ -44,7 +44,8 @@ template <int V, bool PLANAR> __host__ __device__ __forceinline__ int mask_image
 
 // Body of K1 for block (cblk, b): `sm` [P] floats of LDS.  With Ys != nullptr the mask is gathered
 // here from the int64 label map (K0 fused: nearest resize, model/common.py:189-190) and the block
-// with cblk == 0 also writes mask[b,:] and cnt[b] for the backward pass; otherwise it is read from `mask`.
+// with cblk == 0 also writes mask[b,:] and cnt[b] for the backward pass; otherwise it is read from `mask` (and
+// with cnt != nullptr the block with cblk == 0 still writes cnt[b]: mask_resize_flat_kernel leaves it to us).
 // LONG: rows of more than 512 vectors (P > 2048 fp32 / 4096 bf16 elements) -- a separate instantiation, so that
 // the register sets of the two streaming loops do not add up in one kernel.
 template <typename T, bool LONG = false>
@@ -191,8 +192,20 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
         }
     } else {
+        float acc = 0.f;
 #pragma unroll 8
-        for (int p = threadIdx.x; p < P; p += 256) sm[midx(p)] = mrow[p];
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const float m = mrow[p];
+            sm[midx(p)] = m;
+            acc += m;
+        }
+        if (cnt != nullptr && cblk == 0) {                 // (mask resized by a launch that leaves the count to us)
+            acc = wave_sum(acc);
+            float* red = sm + MP;
+            if (lane == 0) red[wave] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) cnt[b] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
     }
     __syncthreads();
 

@@ -54,6 +54,30 @@ __global__ __launch_bounds__(MR_T) void mask_resize_kernel(const int64_t* __rest
     }
 }
 
+// The same resize without the count, flat over all images (thread <-> four elements of [B * P]): for the fused
+// step, where one block per image leaves most of the chip idle (80 images at C5) and the pooling kernel's first
+// channel block of an image sums the row it stages anyway.
+#define MRF_E 4
+__global__ __launch_bounds__(256) void mask_resize_flat_kernel(const int64_t* __restrict__ Ys, int H, int W, int h, int w,
+                                                               int total, float* __restrict__ mask) {
+    const int P = h * w;
+    const float sy = nearest_scale(H, h), sx = nearest_scale(W, w);
+    const int e0 = blockIdx.x * (256 * MRF_E) + threadIdx.x;
+    int64_t lv[MRF_E];
+#pragma unroll
+    for (int u = 0; u < MRF_E; ++u) {
+        const int e = min(e0 + 256 * u, total - 1);
+        const int b = e / P, p = e - b * P;
+        const int y = p / w, x = p - y * w;
+        lv[u] = Ys[((int64_t)b * H + nearest_src(y, sy, H)) * W + nearest_src(x, sx, W)];
+    }
+#pragma unroll
+    for (int u = 0; u < MRF_E; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < total) mask[e] = (float)lv[u];
+    }
+}
+
 #include "dev_masked_sum.hpp"
 
 // ---------------------------------------------------------------------------
@@ -173,9 +197,12 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     // 1 / 0 / 2); the extra launch costs ~4 us, which only small batches cannot afford (C2 step: 88.7 vs 87.2 us
     // at 40 images, 160.5 vs 161.7 us at 80).
     if (P >= 4096 || B >= 64) {
-        int rc = denet_mask_resize(Ys, B, H, W, h, w, mask, cnt, stream);
-        if (rc) return rc;
-        Ys = nullptr;
+        if (!fits_int(B * P)) return DENET_E_UNSUPPORTED;
+        const int total = (int)(B * P);
+        hipLaunchKernelGGL(mask_resize_flat_kernel, dim3((unsigned)((total + 256 * MRF_E - 1) / (256 * MRF_E))), dim3(256),
+                           0, (hipStream_t)stream, Ys, (int)H, (int)W, (int)h, (int)w, total, mask);
+        DENET_CHECK_LAUNCH();
+        Ys = nullptr;                                 // the pooling blocks read `mask`; block 0 of an image writes cnt
     }
     if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
     if (int rc = launch_pool(Fs, feat_dtype, Ys, mask, cnt, S, (int)C, (int)P, rpb, (int)H, (int)W, (int)h, (int)w, W1,
