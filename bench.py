@@ -340,10 +340,18 @@ def main():
         ach = kb[probe] / (probe_us * 1e-6) / 1e9
         # the dominant kernel (the fused up-sampling + loss launch) is bound by VALU issue, not by HBM or
         # MFMA; its HBM fraction is reported because the contract prices kernels against HBM or MFMA only
+        traffic = pmc_traffic(probe, args.config, N)
+        two_launches = probe == "masked_pool_fwd" and (N * way * shape.shot >= 64 or shape.h * shape.w >= 4096)
+        if two_launches and traffic is not None:
+            traffic += pmc_traffic("mask_resize", args.config, N) or 0
         roofline = {"kernel": probe, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(probe, args.config, N),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": kb[probe], "us_per_launch": round(probe_us, 2),
                     "probed_steps": len(pairs) if pairs else 0, "us_per_launch_stat": "median of the probed steps"}
+        if two_launches:
+            # from 64 support images (or 64 x 64 features) on, the pooling stage is two launches and the probe
+            # brackets both; rocprofv3 lists mask_resize_flat_kernel and masked_sum_fwd_kernel apart
+            roofline["launches"] = ["mask_resize", "masked_pool_fwd"]
     # the two Fs-sized HBM streams, from the untimed per-kernel pass (event pair around each launch)
     streams = {k: {"us_per_launch": round(breakdown[k], 2), "bytes_per_launch": kb[k],
                    "achieved": round(kb[k] / (breakdown[k] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
