@@ -133,6 +133,28 @@ def test_c5_bf16_large_resolution_against_oracle(dev):
     _confmat_check(out["logits_full"], ep, s.K, dev)
 
 
+@pytest.mark.parametrize("feat_dtype", ["f32", "bf16"])
+def test_c2_sixteen_episodes_batch_paths_against_oracle(dev, feat_dtype):
+    """C2's shape at 16 episodes takes the batch paths of the K <= 32 kernels: 432 position tiles -> the
+    wave-per-tile forward classifier (from 384 tiles on), 80 support images -> the flat mask resize with the count
+    written by the pooling kernel (from 64 images on), 7 tile groups per episode in the persistent backward; bf16
+    also runs the planar mask image of both streaming kernels on short rows."""
+    from denet_amd.synthetic import CONFIGS, EpisodeShape
+    from oracle import denet_oracle as O
+    s = EpisodeShape(**{**CONFIGS["C2"].asdict(), "N": 16, "feat_dtype": feat_dtype})
+    ep, state, out = _run_step(s, dev)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    gtol = 8e-3 if feat_dtype == "bf16" else 2e-5           # feature gradients are rounded to bf16 on the way out
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["logits_binary"].cpu(), ref["logits_binary"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(out["loss_p"].cpu(), ref["loss_p"]) < 1e-4
+    assert rel_err(out["Fq"].grad.float().cpu(), ref["dFq"]) < gtol
+    assert rel_err(out["Fs"].grad.float().cpu(), ref["dFs"]) < gtol
+    for k, t in zip(ORDER, out["P"]):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
+
+
 def test_properties_at_full_size(dev):
     """Size-independent properties on C2: classifier linearity, masked-gradient support."""
     from denet_amd import ops
