@@ -265,7 +265,12 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    dbg_ev = None
+    if os.environ.get("DENET_BENCH_DEBUG") and graph is None:
+        dbg_ev = (Event(), Event())
     t0 = time.perf_counter()
+    if dbg_ev:
+        dbg_ev[0].record(stream)
     host_us = []
     for i in range(args.steps):
         h0 = time.perf_counter()
@@ -276,10 +281,16 @@ def main():
                 eng.set_probe(None, None, None)
         runner()
         host_us.append((time.perf_counter() - h0) * 1e6)
+    if dbg_ev:
+        dbg_ev[1].record(stream)
+    t_enq = time.perf_counter()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
+    if dbg_ev:
+        dbg("timed region: host %.1f us (enqueue done at %.1f us), first-to-last event on the stream %.1f us" % (
+            (t1 - t0) * 1e6, (t_enq - t0) * 1e6, dbg_ev[0].elapsed_ms(dbg_ev[1]) * 1e3))
     dbg("host us per step: median %.1f, max %.1f, over 200 us: %s" % (
         statistics.median(host_us), max(host_us), [(i, round(h)) for i, h in enumerate(host_us) if h > 200][:20]))
     eng.set_probe(None, None, None)
