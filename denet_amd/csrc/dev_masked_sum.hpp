@@ -319,11 +319,17 @@ struct CoefArgs {
     float Pf, eps;
 };
 
-// NT: non-temporal stores.  A dFs stream larger than the 256 MB last-level cache leaves that cache full of dirty
-// lines whose write-back the NEXT streaming kernel pays for (the pooling kernel of the next step: 117 us after a
-// cached 344 MB dFs stream, 89 us otherwise; scripts/diag/pool_after_dfs.py); sent around the cache the stream
-// costs this kernel 10 us more and the next one 26 us less.  Below that size the cache absorbs the stream and
-// cached stores are faster for both (the launcher picks).
+// NT: non-temporal stores.  A cached dFs stream leaves the last-level cache full of dirty lines whose write-back
+// the NEXT streaming kernels pay for (the pooling kernel of the next step: 117 us after a cached 344 MB dFs
+// stream, 89 us otherwise; scripts/diag/pool_after_dfs.py); sent around the cache the stream costs this kernel
+// ~10-25 us more and the next one more than that less.  Only when the step's whole working set fits the 256 MB
+// cache (C2 at 8 episodes: 69 MB of dFs) are cached stores faster for both; the launcher picks
+// (head_step.hip: 80 MB).
+// bf16 keeps the row-per-wave writer with non-temporal stores (the flat writer's per-element plane arithmetic
+// makes it VALU-bound there: C5 B3 97 us flat against 86 us by rows)
+#ifndef DENET_NT_BF16_ROWS
+#define DENET_NT_BF16_ROWS 1
+#endif
 template <typename T, int NSLT, bool NT = false>      // NSLT = C/16 for the sliced chain, 0: coef is given
 __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ mask, const float* __restrict__ coef,
                                                     T* __restrict__ dFs, int C, int P, int rows_per_block, int b,
@@ -390,7 +396,8 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
     __syncthreads();
 
     typedef typename Vec16<T>::type vec_t;
-    if constexpr (!NT) {
+    constexpr bool ROWS = !NT || (V == 8 && DENET_NT_BF16_ROWS);
+    if constexpr (ROWS) {
         // streams the last-level cache absorbs (C2, C5): one wave per channel row, four rows of a block in flight
         // (measured against the flat writer below: 17.1 vs 17.7 us at C2, 69.4 vs 71.4 us at C5)
         for (int r = wave; r < rows_per_block; r += 4) {
@@ -417,7 +424,8 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
                     if constexpr (V == 4) v[e] = x;
                     else v[e] = f32_to_bf16(x);
                 }
-                rv[i] = v;
+                if constexpr (NT) __builtin_nontemporal_store(v, rv + i);
+                else rv[i] = v;
             }
             const int t0 = head + nvec * V;
             if (t0 + lane < P) FeatIO<T>::store(row + t0 + lane, k * sm[midx(t0 + lane)]);

@@ -369,9 +369,11 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        // dFs streams that do not fit the 256 MB last-level cache go around it (dev_masked_sum.hpp, NT);
-        // measured break-even between C5 (269 MB of bf16: cached stores win) and C3 (344 MB of fp32: NT wins)
-        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)320 << 20);
+        // dFs streams go around the caches (dev_masked_sum.hpp, NT) unless the whole step's working set stays
+        // resident in the 256 MB last-level cache.  Measured (C2 shape, fp32, step time cached vs NT): 69 MB
+        // 86.9 vs 90.7 us, 103 MB 127.8 vs 125.3, 138 MB 161.5 vs 144.2, 207 MB 221.6 vs 204.9, 275 MB 287.1 vs
+        // 260.1; bf16 at C5's shape: 67 MB 158.7 vs 156.4, 134 MB 250.1 vs 238.0, 269 MB 427.1 vs 418.6.
+        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)80 << 20);
         // LDS: the mask image of the dFs blocks (dev_masked_sum.hpp) + their 64 + 16 floats
         size_t lds = (size_t)((f32 ? (nt ? mask_image_floats<4, MaskImage<float, true>::PLANAR>((int)P)
                                          : mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P))
