@@ -48,7 +48,12 @@ template <int V, bool PLANAR> __host__ __device__ __forceinline__ int mask_image
 // with cnt != nullptr the block with cblk == 0 still writes cnt[b]: mask_resize_flat_kernel leaves it to us).
 // LONG: rows of more than 512 vectors (P > 2048 fp32 / 4096 bf16 elements) -- a separate instantiation, so that
 // the register sets of the two streaming loops do not add up in one kernel.
-template <typename T, bool LONG = false>
+// NTL: the feature stream is read with non-temporal loads.  Fs is read once per step; once the step's working set
+// is larger than the 256 MB last-level cache, letting the stream through the cache evicts what IS re-read (Fq by
+// the classifier forward and backward, the logits and their gradient slabs) and the stream itself runs slower:
+// C3 step 354.8 -> 337.3 us (F1 84 -> 74), C5 420.5 -> 397.9 us (F1 74 -> 62); at C2 (8 episodes, everything
+// stays resident) 87.7 -> 91.0 us the other way, so the launcher picks by size like it does for the dFs stores.
+template <typename T, bool LONG = false, bool NTL = false>
 __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, const int64_t* __restrict__ Ys,
                                                     float* __restrict__ mask, float* __restrict__ cnt,
                                                     float* __restrict__ S, int C, int P, int rows_per_block, int H,
@@ -80,6 +85,10 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
                 *reinterpret_cast<const f32x4*>(W1 + (int64_t)min(wog + 64 * m, C - 1) * C + c0 + 4 * wq);
     };
     typedef typename Vec16<T>::type vec_t;
+    auto fs_load = [](const vec_t* p) {
+        if constexpr (NTL) return __builtin_nontemporal_load(p);
+        else return *p;
+    };
     constexpr int NV = 8;                                 // vector loads per lane per row on the fast path
     constexpr int NR = 2;                                 // rows of a wave in flight together (more costs occupancy)
     constexpr bool short_rows = !LONG;                    // the launcher picks: P / V <= NV * 64
@@ -106,7 +115,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
             hv[q] = FeatIO<T>::load(row + min(lane, P - 1));
             tv[q] = FeatIO<T>::load(row + min(head + nvec * V + lane, P - 1));
 #pragma unroll
-            for (int u = 0; u < NV; ++u) v[q][u] = rv[min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0)];
+            for (int u = 0; u < NV; ++u) v[q][u] = fs_load(rv + min(lane + 64 * u, nvec > 0 ? nvec - 1 : 0));
         }
     };
     // mask[head + V i + e] for vector i = lane + (immediate): one LDS address per plane (row-major: one in all)
@@ -242,7 +251,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         vec_t va[NV], vb[NV];
         auto fetch = [&](int i0, vec_t (&vv)[NV]) {
 #pragma unroll
-            for (int u = 0; u < NV; ++u) vv[u] = rv[max(min(i0 + 64 * u, nvec - 1), 0)];
+            for (int u = 0; u < NV; ++u) vv[u] = fs_load(rv + max(min(i0 + 64 * u, nvec - 1), 0));
         };
         const float* pb[V];
         plane_bases(head, pb);
@@ -276,7 +285,7 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
 
 // (short rows, fp32: 134 VGPRs, 3 waves per SIMD; forcing 4 with amdgpu_waves_per_eu spills 7 registers and the
 // stream runs 10 % slower at every batch size: more resident blocks do not buy bandwidth)
-template <typename T, bool LONG>
+template <typename T, bool LONG, bool NTL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void masked_sum_fwd_kernel(const T* __restrict__ Fs,
                                                             const int64_t* __restrict__ Ys,
                                                             float* __restrict__ mask, float* __restrict__ cnt,
@@ -289,8 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void m
     const int ncb = (C + rows_per_block - 1) / rows_per_block;
     const int v = xcd_swizzle(blockIdx.x, gridDim.x);
     BSTAMP(0);
-    masked_sum_fwd_body<T, LONG>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
-                                 pre1_part);
+    masked_sum_fwd_body<T, LONG, NTL>(Fs, Ys, mask, cnt, S, C, P, rows_per_block, H, W, h, w, v / ncb, v % ncb, sm, W1,
+                                      pre1_part);
     BSTAMP(1);
 }
 

@@ -114,18 +114,27 @@ static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float*
     const size_t lds = (size_t)((f32 ? (longr ? mask_image_floats<4, MaskImage<float, false>::PLANAR>(P)
                                           : mask_image_floats<4, MaskImage<float, true>::PLANAR>(P))
                                    : mask_image_floats<8, true>(P)) + 4 + 16) * 4 + (W1 ? 256 * 64 : 0);
+#define POOL_GO2(TT, LG, NL)                                                                                      \
+    do {                                                                                                          \
+        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_fwd_kernel<TT, LG, NL>), lds))      \
+            return DENET_E_LAUNCH;                                                                                \
+        hipLaunchKernelGGL((masked_sum_fwd_kernel<TT, LG, NL>), grid, dim3(256), lds, st, (const TT*)Fs, Ys, mask, cnt, S, \
+                           C, P, rpb, H, W, h, w, W1, pre1_part);                                                 \
+    } while (0)
 #define POOL_GO(TT, LG)                                                                                           \
     do {                                                                                                          \
-        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_fwd_kernel<TT, LG>), lds))          \
-            return DENET_E_LAUNCH;                                                                                \
-        hipLaunchKernelGGL((masked_sum_fwd_kernel<TT, LG>), grid, dim3(256), lds, st, (const TT*)Fs, Ys, mask, cnt, S, C, \
-                           P, rpb, H, W, h, w, W1, pre1_part);                                                    \
+        if (ntl) POOL_GO2(TT, LG, true); else POOL_GO2(TT, LG, false);                                            \
     } while (0)
+    // feature streams of more than 160 MB are read around the caches (dev_masked_sum.hpp, NTL).  Step time
+    // without / with, C2's shape: 138 MB 144.2 / 147.1 us, 172 MB 175.7 / 172.9, 207 MB 204.6 / 192.6, 241 MB
+    // 243.6 / 228.9; C5's shape (bf16): 134 MB 237.1 / 237.0, 202 MB 332.9 / 316.1, 269 MB 420.5 / 397.9
+    const bool ntl = (int64_t)grid.x * rpb * P * (f32 ? 4 : 2) > ((int64_t)160 << 20);
     if (f32) {
         if (longr) POOL_GO(float, true); else POOL_GO(float, false);
     } else {
         if (longr) POOL_GO(unsigned short, true); else POOL_GO(unsigned short, false);
     }
+#undef POOL_GO2
 #undef POOL_GO
     return DENET_OK;
 }
