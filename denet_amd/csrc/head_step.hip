@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * B1_NW) void head_bwd_dwn_kernel(ClsBwdArgs g, 
 }
 
 // K > 32: persistent blocks (dev_classify.hpp, classify_bwd_wide_body); g.n_part = groups per episode
-template <typename T, int RT>
+template <typename T, int RT, bool NTQ>
 __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsBwdArgs g, ClsBwdArgs g2,
                                                                             const float* __restrict__ part_p, int NB,
                                                                             int parts_p, float* __restrict__ losses) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsB
             loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
         }
     } else {
-        classify_bwd_wide_body<T, RT, false>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+        classify_bwd_wide_body<T, RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
     }
 }
 
@@ -121,10 +121,18 @@ static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
     if (wide) {                         // persistent blocks (quad loads need P >= 4; see cls_bwd_parts below)
         const size_t ldw = CLW_BWD_LDS(RT);
-        if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT>), ldw))
-            return DENET_E_LAUNCH;
-        hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT>), dim3((unsigned)(2 * n_part), (unsigned)N),
-                           dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+        // dFq streams up to 80 MB leave with non-temporal stores (dev_classify.hpp, NTQ)
+        if ((int64_t)N * g.C * g.P * (int64_t)sizeof(T) <= ((int64_t)80 << 20)) {
+            if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT, true>), ldw))
+                return DENET_E_LAUNCH;
+            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+        } else {
+            if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT, false>), ldw))
+                return DENET_E_LAUNCH;
+            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+        }
         return DENET_OK;
     }
     const size_t lds = CLS_BWD_LDS_NW(g.K, B1_NW);
