@@ -253,6 +253,9 @@ def main():
         # enqueued the kernel and the pair reads the host's launch time too (25 us against 18.5 for F1 at C2)
         first = 1 if args.steps > 8 * every else 0
         pairs = {i: (Event(), Event()) for i in range(first, args.steps, every)}
+        if every < args.probe_every:
+            # short regions (the driver's 20 steps): exactly 8 samples -- every pair costs ~3 us of stream time
+            pairs = dict(list(pairs.items())[:8])
     # no collector pause inside a timed loop: re-binding for the probes allocates closures, and a full collection
     # of torch's object graph (measured 42 ms, once) would be charged to whichever step triggers it
     gc.collect()
