@@ -267,7 +267,7 @@ def main():
     # sustained clocks (20 timed steps read 95.3 us/step after the idle gap, 90.5 us in a 300-step run)
     # Settling run first (untimed set-up, like the breakdown pass above): so far the GPU has idled between short
     # synchronised bursts, and W = 5 warm-up steps (0.4 ms) do not bring it to its sustained state.
-    for _ in range(args.settle):
+    for _ in range(0 if host_reduce else args.settle):      # (gloo dry runs reduce through host memory: ms per step)
         runner()
     for _ in range(max(args.warmup, 2)):
         runner()
