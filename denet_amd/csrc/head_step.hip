@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
     }
 }
 
+#ifndef DENET_DFS_NT_MB
+#define DENET_DFS_NT_MB 80          // dFs streams above this size leave with non-temporal stores (see B3 below)
+#endif
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
@@ -381,7 +384,7 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         // resident in the 256 MB last-level cache.  Measured (C2 shape, fp32, step time cached vs NT): 69 MB
         // 86.9 vs 90.7 us, 103 MB 127.8 vs 125.3, 138 MB 161.5 vs 144.2, 207 MB 221.6 vs 204.9, 275 MB 287.1 vs
         // 260.1; bf16 at C5's shape: 67 MB 158.7 vs 156.4, 134 MB 250.1 vs 238.0, 269 MB 427.1 vs 418.6.
-        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)80 << 20);
+        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)DENET_DFS_NT_MB << 20);
         // LDS: the mask image of the dFs blocks (dev_masked_sum.hpp) + their 64 + 16 floats
         size_t lds = (size_t)((f32 ? (nt ? mask_image_floats<4, MaskImage<float, true>::PLANAR>((int)P)
                                          : mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P))
