@@ -24,23 +24,21 @@ import gc
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from denet_amd import _lib                                    # noqa: E402
-from denet_amd.engine import HeadStepEngine, PARAM_ORDER      # noqa: E402
-from denet_amd.hiprt import Event                             # noqa: E402
-from denet_amd.synthetic import CONFIGS, EpisodeShape, make_episodes, make_estimator_state  # noqa: E402
+# torch and denet_amd are imported inside run(): with `--gpus N` and no WORLD_SIZE this process is only the
+# launcher of N fresh rank processes and must not have touched the GPU (or loaded the library) itself
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+LLC_BYTES = 256 << 20        # last-level (Infinity) cache: the rotating leg's batches must exceed it together
 
 
-def kernel_bytes(s: EpisodeShape, sF: int):
+def kernel_bytes(s, sF: int):
     """Algorithmic bytes per launch of each kernel of the step."""
     N, way, shot, K, C = s.N, s.way, s.shot, s.K, s.c
     B, P, Q, NB = N * way * shot, s.h * s.w, s.H * s.W, N * way
@@ -71,7 +69,26 @@ def kernel_bytes(s: EpisodeShape, sF: int):
     }
 
 
-def step_bytes_per_episode(s: EpisodeShape, sF: int) -> float:
+def kernel_bytes_compulsory(s, sF: int):
+    """SURVEY.md §8d bytes per launch: each input read once per pass that needs it, each output written once;
+    parameters and their slices (L2-resident, 0.81 MB) and split-K partials excluded.  This is what
+    `roofline.achieved` is priced on; kernel_bytes() above (with the parameter re-reads and partial outputs a
+    launch really touches) stays in the line as `bytes_incl_params`."""
+    N, way, shot, K, C = s.N, s.way, s.shot, s.K, s.c
+    B, P, Q, NB = N * way * shot, s.h * s.w, s.H * s.W, N * way
+    return {
+        "masked_pool_fwd": B * C * P * sF + B * P * 8,                        # Fs + the sampled mask elements
+        "proto_extend_fwd": 0,
+        "classify_fwd": N * C * P * sF + N * K * P * 4 + NB * 2 * P * 4,      # Fq in, both logit tensors out
+        "loss_pair_fwd": N * Q * 8 + NB * Q * 8 + N * K * P * 4 + NB * 2 * P * 4 + 2 * N * K * P * 4,
+        "loss_finalize": 0,
+        "bwd_dwn": 2 * N * K * P * 4 + N * C * P * sF + N * C * P * sF,       # slabs re-read, Fq re-read, dFq out
+        "bwd_chain_dfq": 0,
+        "bwd_params_dfs": B * C * P * sF + B * P * 8,                         # dFs out + the mask row (§8d: w*s*P*8)
+    }
+
+
+def step_bytes_per_episode(s, sF: int) -> float:
     """SURVEY.md §8d formula (compulsory traffic per episode, fwd + bwd, with loss_p)."""
     w_, sh, K, C = s.way, s.shot, s.K, s.c
     P, Q = s.h * s.w, s.H * s.W
@@ -97,12 +114,14 @@ def pmc_traffic(kernel: str, config: str, episodes: int):
     return run.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node to run on, one rank each.  Under torchrun (WORLD_SIZE set) it must equal "
+                         "the world size; without it and N > 1 this process starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4a", "C4b", "C5"])
     ap.add_argument("--episodes", type=int, default=0, help="episodes per GPU (default: the config's batch)")
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured HIP graph")
     ap.add_argument("--probe", default="auto", help="kernel to time with HIP events (name | auto | none)")
@@ -121,13 +140,93 @@ def main():
                     help="time the step with train-mode dropout generated inside the kernels (p = 0.5 at both "
                          "sites, a new seed every step) instead of eval mode; the default run reports it beside "
                          "the eval-mode value as `train_mode`")
-    args = ap.parse_args()
-    if args.train_mode and args.graph:
-        raise SystemExit("--train-mode with --graph would replay one captured seed; run them separately")
+    ap.add_argument("--no-rotating", action="store_true",
+                    help="skip the second timed leg that rotates over resident batches larger than the last-level cache")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the leg that drives the same batch through the reference-shaped Python API")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="join the process group, check that all ranks are there, print one line and stop before "
+                         "the first kernel (CPU test of the launch path: DENET_BENCH_BACKEND=gloo)")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the children's exit code.  This process
+    has not touched the GPU: nothing here imports torch.cuda state or the HIP library."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL (see the environment notes)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out or out.startswith('{"dry_run"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run(args)
+
+
+def run(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}: one rank per GPU")
+    backend = os.environ.get("DENET_BENCH_BACKEND", "nccl")
+
+    if args.dry_run:
+        # launch-path check: every rank joins, the group counts them, rank 0 reports; no kernel, no GPU needed
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.ones(1, device=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            t = torch.ones(1)
+        dist.all_reduce(t)
+        joined = int(t.item())
+        assert joined == dist.get_world_size() == args.gpus, (joined, dist.get_world_size(), args.gpus)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size(), "ranks_joined": joined,
+                              "backend": backend}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    from denet_amd import _lib
+    from denet_amd.engine import HeadStepEngine
+    from denet_amd.hiprt import Event
+    from denet_amd.synthetic import CONFIGS, EpisodeShape, make_episodes, make_estimator_state
+
+    if args.train_mode and args.graph:
+        raise SystemExit("--train-mode with --graph would replay one captured seed; run them separately")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one rank per GPU; the modulo only matters for a dry run of the N > 1 path on a one-GPU box
@@ -142,7 +241,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("DENET_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -155,6 +253,18 @@ def main():
     # (scripts/diag_gloo_shared_gpu.py, mode `torch`: both ranks parked in all_reduce after 20-40 calls), so the
     # round-1 hang was not the step's stream ordering.  RCCL (one rank per GPU) reduces the device bucket in place.
     host_reduce = dist is not None and dist.get_backend() != "nccl"
+
+    # every rank on a GPU of its own: the line's n_gpus is the group's size, and the devices are distinct
+    devices = [torch.cuda.current_device()]
+    if dist is not None:
+        assert dist.get_world_size() == world == args.gpus or args.collective, (dist.get_world_size(), world, args.gpus)
+        onehot = torch.zeros(max(torch.cuda.device_count(), world), dtype=torch.int64,
+                             device="cpu" if host_reduce else dev)
+        onehot[torch.cuda.current_device()] = 1
+        dist.all_reduce(onehot)
+        devices = [i for i, c in enumerate(onehot.tolist()) for _ in range(c)]
+        if not host_reduce and int(onehot.max()) > 1:
+            raise SystemExit(f"two ranks share a GPU (ranks per device: {onehot.tolist()}): one rank per GPU")
 
     shape = CONFIGS[args.config]
     if args.episodes > 0:
@@ -176,7 +286,9 @@ def main():
     # the host advances every step (the library reads the struct at each call)
     drop = _lib.Dropout(0x5EED0000 + rank, 0.5, 0.5)
     bind_args = (ep["Fq"], ep["Fs"], ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"], params)
-    eng.bind_step(*bind_args, drop=drop if args.train_mode else None)
+    bound_eval = eng.make_bound(*bind_args, drop=None)
+    bound_train = eng.make_bound(*bind_args, drop=drop)
+    eng.use_bound(bound_train if args.train_mode else bound_eval)
     train_now = [args.train_mode]
 
     def step():
@@ -198,6 +310,24 @@ def main():
             else:
                 dist.all_reduce(eng.grad_bucket, op=reduce_op)
 
+    def timed(fn, steps):
+        """`steps` calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks, seconds."""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_reduce else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     dbg = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("DENET_BENCH_DEBUG") else (lambda m: None)
     if os.environ.get("DENET_BENCH_DEBUG"):
         import faulthandler
@@ -211,6 +341,7 @@ def main():
 
     # ---- per-kernel breakdown (untimed): HIP events around each kernel in turn ----
     kb = kernel_bytes(shape, sF)
+    kc = kernel_bytes_compulsory(shape, sF)
     breakdown = {}
     if args.breakdown or args.probe == "auto":
         e0, e1 = Event(), Event()
@@ -271,17 +402,9 @@ def main():
         runner()
     for _ in range(max(args.warmup, 2)):
         runner()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dbg_ev = None
-    if os.environ.get("DENET_BENCH_DEBUG") and graph is None:
-        dbg_ev = (Event(), Event())
-    t0 = time.perf_counter()
-    if dbg_ev:
-        dbg_ev[0].record(stream)
     host_us = []
-    for i in range(args.steps):
+
+    def timed_step(i):
         h0 = time.perf_counter()
         if pairs:
             if i in pairs:
@@ -290,58 +413,71 @@ def main():
                 eng.set_probe(None, None, None)
         runner()
         host_us.append((time.perf_counter() - h0) * 1e6)
-    if dbg_ev:
-        dbg_ev[1].record(stream)
-    t_enq = time.perf_counter()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    if dbg_ev:
-        dbg("timed region: host %.1f us (enqueue done at %.1f us), first-to-last event on the stream %.1f us" % (
-            (t1 - t0) * 1e6, (t_enq - t0) * 1e6, dbg_ev[0].elapsed_ms(dbg_ev[1]) * 1e3))
+
+    elapsed = timed(timed_step, args.steps)
     dbg("host us per step: median %.1f, max %.1f, over 200 us: %s" % (
         statistics.median(host_us), max(host_us), [(i, round(h)) for i, h in enumerate(host_us) if h > 200][:20]))
     eng.set_probe(None, None, None)
     dbg("timed region done")
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_reduce else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    losses = eng.losses.cpu().tolist()
 
-    # ---- the same step in train mode (in-kernel dropout), timed the same way, reported beside the main line ----
+    # ---- second timed leg: the same step ROTATING over resident batches that together exceed the last-level
+    # cache.  The main leg re-reads one batch every step, and at C2 x 8 its ~200 MB working set stays in the
+    # 256 MB Infinity Cache (what a training loop over fresh batches would not see); here every step's inputs
+    # come from HBM.  Same engine (outputs, gradients, workspace), R pre-bound input sets.
+    rotating = None
+    if not args.no_rotating and graph is None and not host_reduce:
+        in_bytes = sum(ep[k].numel() * ep[k].element_size() for k in ("Fq", "Fs", "Ys", "Yq", "Yq_full", "wgt"))
+        R = max(3, -(-int(1.25 * LLC_BYTES) // in_bytes))
+        bounds = [bound_train if args.train_mode else bound_eval]
+        keep = []
+        for j in range(1, R):
+            e2 = {k: v.to(dev).contiguous() for k, v in make_episodes(shape, seed_offset=1000 * rank + 31 * j).items()}
+            keep.append(e2)
+            bounds.append(eng.make_bound(e2["Fq"], e2["Fs"], e2["Ys"], e2["label"].reshape(N, way).contiguous(),
+                                         e2["Yq"], e2["Yq_full"], e2["wgt"], params,
+                                         drop=drop if args.train_mode else None))
+
+        def rot_step(i):
+            eng.use_bound(bounds[i % R])
+            step()
+
+        for i in range(max(args.warmup, 2 * R)):
+            rot_step(i)
+        el_r = timed(rot_step, args.steps)
+        eng.use_bound(bounds[0])
+        rotating = {"value": round(N * world * args.steps / el_r, 1), "unit": "episodes/s",
+                    "ms_per_step": round(el_r / args.steps * 1e3, 4), "batches": R,
+                    "input_bytes_per_batch": in_bytes,
+                    "note": "inputs rotate over %d resident batches (%.0f MB in total, last-level cache 256 MiB); "
+                            "outputs / gradients / workspace are the engine's own buffers" % (R, R * in_bytes / 1e6)}
+        del keep, bounds
+
+    # ---- train mode (in-kernel dropout) beside eval mode: alternating segments of `steps` steps each, so that
+    # both readings come from the same number of steps under the same clocks (a single 20-step region carries
+    # +-2 % of noise, more than the ~1.5 us the generator costs) ----
     train_line = None
     if not args.train_mode and graph is None:
-        eng.bind_step(*bind_args, drop=drop)
-        train_now[0] = True
-        for _ in range(5):
-            step()
-        if dist is not None:
-            dist.barrier()
+        seg = {False: [], True: []}
+        for rep in range(3):
+            for mode in (False, True):
+                eng.use_bound(bound_train if mode else bound_eval)
+                train_now[0] = mode
+                for _ in range(5):
+                    step()
+                seg[mode].append(timed(lambda i: step(), args.steps))
+        train_now[0] = False
+        el_e, el_t = statistics.median(seg[False]), statistics.median(seg[True])
         torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el2 = time.perf_counter() - t2
-        if dist is not None:
-            t = torch.tensor([el2], dtype=torch.float64, device="cpu" if host_reduce else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        train_line = {"value": round(N * world * args.steps / el2, 1), "unit": "episodes/s",
-                      "ms_per_step": round(el2 / args.steps * 1e3, 4),
+        train_line = {"value": round(N * world * args.steps / el_t, 1), "unit": "episodes/s",
+                      "ms_per_step": round(el_t / args.steps * 1e3, 4),
+                      "ms_per_step_eval_interleaved": round(el_e / args.steps * 1e3, 4),
+                      "segments": "3 alternating pairs of %d-step regions (eval, train), medians" % args.steps,
                       "dropout": "Philox4x32-10 in F2 / F3 / B2, p=0.5 gate and class weights, new seed per step",
                       "loss_k": float(eng.losses[0].item())}
-        train_now[0] = False
-        gc.enable()
-        eng.bind_step(*bind_args, drop=None)
-        step()                                   # eng.losses back to the eval-mode values reported below
-        torch.cuda.synchronize()
-
+        eng.use_bound(bound_eval)
     gc.enable()
+
     probe_us = None
     if pairs:
         samples = [a.elapsed_ms(b) * 1e3 for a, b in pairs.values()]
@@ -350,14 +486,15 @@ def main():
     elif probe:
         probe_us = breakdown.get(probe)
 
-    losses = eng.losses.cpu().tolist()
     episodes = N * world * args.steps
     value = episodes / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     roofline = None
     if probe and probe_us:
-        ach = kb[probe] / (probe_us * 1e-6) / 1e9
+        # algorithmic (compulsory) bytes of the launch / its measured duration
+        nbytes = kc[probe] or kb[probe]
+        ach = nbytes / (probe_us * 1e-6) / 1e9
         # the dominant kernel (the fused up-sampling + loss launch) is bound by VALU issue, not by HBM or
         # MFMA; its HBM fraction is reported because the contract prices kernels against HBM or MFMA only
         traffic = pmc_traffic(probe, args.config, N)
@@ -366,20 +503,26 @@ def main():
             traffic += pmc_traffic("mask_resize", args.config, N) or 0
         roofline = {"kernel": probe, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": kb[probe], "us_per_launch": round(probe_us, 2),
+                    "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of this command, committed; not re-measured in this run)"
+                                      if traffic is not None else None,
+                    "bytes_per_launch": nbytes, "bytes_definition": "SURVEY.md 8d compulsory bytes",
+                    "bytes_incl_params": kb[probe], "us_per_launch": round(probe_us, 2),
                     "probed_steps": len(pairs) if pairs else 0, "us_per_launch_stat": "median of the probed steps"}
         if two_launches:
             # from 64 support images (or 64 x 64 features) on, the pooling stage is two launches and the probe
             # brackets both; rocprofv3 lists mask_resize_flat_kernel and masked_sum_fwd_kernel apart
             roofline["launches"] = ["mask_resize", "masked_pool_fwd"]
     # the two Fs-sized HBM streams, from the untimed per-kernel pass (event pair around each launch)
-    streams = {k: {"us_per_launch": round(breakdown[k], 2), "bytes_per_launch": kb[k],
-                   "achieved": round(kb[k] / (breakdown[k] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(kb[k] / (breakdown[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    streams = {k: {"us_per_launch": round(breakdown[k], 2), "bytes_per_launch": kc[k],
+                   "achieved": round(kc[k] / (breakdown[k] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(kc[k] / (breakdown[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                for k in ("masked_pool_fwd", "bwd_params_dfs") if k in breakdown}
     spb = step_bytes_per_episode(shape, sF)
     step_roof = {"bytes_per_episode": spb, "achieved": round(value / world * spb / 1e9, 1), "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": round(value / world * spb / 1e9 / HBM_PEAK_GBS, 4)}
+    if rotating is not None:
+        step_roof["frac_rotating"] = round(rotating["value"] / world * spb / 1e9 / HBM_PEAK_GBS, 4)
 
     # the box's own stream-copy ceiling (read + write bytes of a 512 MiB device copy), for reading the
     # fractions above against what this HBM delivers rather than the 8 TB/s specification
@@ -397,6 +540,11 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = round(10 * 2 * a.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
         del a, b
+
+    # ---- the drop-in API on the same batch (rank 0): what a user of the reference calls ----
+    dropin = None
+    if rank == 0 and not args.no_dropin and graph is None:
+        dropin = dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.collective:
@@ -417,10 +565,14 @@ def main():
                          f"median {med * 1e3:.0f} ms/step"}
 
     if rank == 0:
+        n_gpus = dist.get_world_size() if dist is not None else 1
+        assert n_gpus == world
+        ws_mb = (eng.ws_bytes + eng.dFs.numel() * eng.dFs.element_size() + eng.dFq.numel() * eng.dFq.element_size()
+                 + sum(ep[k].numel() * ep[k].element_size() for k in ep)) / 1e6
         out = {
             "metric": "DENet head episodes/sec fwd+bwd (1-way 5-shot)" if args.config == "C2"
                       else f"DENet head episodes/sec fwd+bwd ({args.config})",
-            "value": round(value, 1), "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "episodes/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "settle_steps": args.settle, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if sF == 4 else "bf16-in/f32-acc",
@@ -428,18 +580,66 @@ def main():
             "config": {"workload": f"{args.config}: {way}-way {shape.shot}-shot head fwd+bwd, K={shape.K}, "
                                    f"features {shape.c}x{shape.h}x{shape.w}, labels {shape.H}x{shape.W}",
                        "episodes_per_gpu": N, "global_batch": N * world, "parallelism": f"dp{world} (episode-sharded)",
-                       "graph_replay": bool(graph),
-                       "mode": "train (in-kernel dropout, p=0.5)" if args.train_mode else "eval (no dropout)"},
+                       "graph_replay": bool(graph), "devices": devices,
+                       "mode": "train (in-kernel dropout, p=0.5)" if args.train_mode else "eval (no dropout)",
+                       "residency": "one batch re-read every step; working set %.0f MB %s the 256 MiB last-level "
+                                    "cache (see value_rotating)" % (ws_mb, "fits" if ws_mb * 1e6 < LLC_BYTES else "exceeds")},
+            "value_rotating": rotating["value"] if rotating else None, "rotating": rotating,
             "roofline": roofline, "step_roofline": step_roof, "hbm_stream_kernels": streams,
-            "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu, "train_mode": train_line,
+            "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu, "train_mode": train_line, "dropin": dropin,
             "kernels_us": {k: round(v, 2) for k, v in breakdown.items()},
             "loss_k": losses[0], "loss_p": losses[1],
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=60):
+    """The same batch through the reference-shaped Python API, fwd + both losses + loss_k.backward(), us per
+    step (host-synchronised loop of `steps` steps after 10 warm-up steps):
+      * `head_step`: WeightEstimator.head_step -- what DENet.forward_step / DENetTrainer.step run: ONE
+        HeadStepFunction node = the seven launches the headline times, plus torch's autograd / allocator and the
+        ctypes argument conversion on the host;
+      * `standalone`: WeightEstimator.forward_with_binary + loss_denet_batch + backward -- the stand-alone
+        kernel chain (one autograd node per reference call), the drop-in path of rounds 1-2."""
+    from denet_amd.head import WeightEstimator
+    from denet_amd.losses import loss_denet_batch
+    we = WeightEstimator(shape.K, shape.c).to(dev).eval()
+    we.load_state_dict(state_cpu)
+    Fq = ep["Fq"].detach().clone().requires_grad_(True)
+    Fs = ep["Fs"].detach().clone().requires_grad_(True)
+
+    def fused():
+        lk, lp, full, binl = we.head_step(Fq, Fs, ep["Ys"], labels, ep["Yq"], ep["Yq_full"], ep["wgt"])
+        lk.backward()
+
+    def standalone():
+        full, binl = we.forward_with_binary(Fq, Fs, ep["Ys"], labels)
+        lk, lp = loss_denet_batch(full, ep["Yq_full"], binl, ep["Yq"], ep["wgt"])
+        lk.backward()
+
+    res = {}
+    for name, fn in (("head_step", fused), ("standalone", standalone)):
+        for _ in range(10):
+            we.zero_grad(set_to_none=True)
+            Fq.grad = Fs.grad = None
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            we.zero_grad(set_to_none=True)
+            Fq.grad = Fs.grad = None
+            fn()
+        torch.cuda.synchronize()
+        res[name + "_us_per_step"] = round((time.perf_counter() - t0) / steps * 1e6, 1)
+    res["steps"] = steps
+    res["episodes_per_s_head_step"] = round(shape.N / (res["head_step_us_per_step"] * 1e-6), 1)
+    res["note"] = ("eval mode, same C-ABI kernels as the headline; head_step = WeightEstimator.head_step "
+                   "(DENet.forward_step / DENetTrainer.step), standalone = forward_with_binary + loss_denet_batch")
+    return res
 
 
 if __name__ == "__main__":

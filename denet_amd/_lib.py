@@ -59,6 +59,7 @@ _NOSTREAM = {
     "denet_classify_bwd_parts": (ctypes.c_int64, "l"),
     "denet_head_step_workspace": (ctypes.c_int64, "lllllllll"),
     "denet_upsample_loss_parts": (ctypes.c_int64, "llllli"),
+    "denet_head_step_plan": (ctypes.c_int, "lllllllllih"),
 }
 _CT = {"p": ctypes.c_void_p, "F": ctypes.c_void_p, "L": ctypes.c_void_p, "l": ctypes.c_int64, "u": ctypes.c_uint64, "i": ctypes.c_int, "f": ctypes.c_float, "h": ctypes.c_void_p}
 
@@ -76,6 +77,27 @@ class Dropout(ctypes.Structure):
 
 
 DROPOUT_GATE, DROPOUT_WEIGHT = 1, 2                     # stream ids of denet_dropout_mask
+
+
+class StepPlan(ctypes.Structure):
+    """denet_step_plan_t (include/denet_hip.h): which kernel variant each launch of the fused step runs."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "pool_launches", "pool_long_rows", "pool_nt_loads", "classify_layout", "classify_groups",
+        "loss_chain_cell", "loss_chunk", "loss_xsplit", "bwd_persistent", "bwd_groups", "bwd_dfq_nt",
+        "dfs_nt", "dfs_flat_writer")] + [("reserved", ctypes.c_int32 * 3)]
+
+
+CLS_TILE8, CLS_UNITS, CLS_WAVE4 = 0, 1, 2
+
+
+def head_step_plan(N, way, shot, K, C, h, w, H, W, feat_dtype=None):
+    """dict of the launchers' choices for a shape (denet_head_step_plan); feat_dtype: torch dtype or F32 / BF16."""
+    code = feat_dtype if isinstance(feat_dtype, int) else (BF16 if feat_dtype == torch.bfloat16 else F32)
+    plan = StepPlan()
+    rc = load().denet_head_step_plan(N, way, shot, K, C, h, w, H, W, code, ctypes.byref(plan))
+    if rc != 0:
+        raise DenetHipError(f"denet_head_step_plan failed: {strerror(rc)} (code {rc})")
+    return {n: int(getattr(plan, n)) for n, _ in StepPlan._fields_ if n != "reserved"}
 
 
 # the launches of the fused step (include/denet_hip.h, DENET_K_*)

@@ -797,28 +797,41 @@ static int set_lds(KernelT kern, size_t lds) {
     return denet_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
 }
 
+// Forward layout for a shape (also reported by denet_head_step_plan): DENET_CLS_TILE8 = eight waves per
+// 64-position tile (K <= 32, few tiles), DENET_CLS_UNITS = layout (a) below, DENET_CLS_WAVE4 = layout (b).
+// `groups` (layout (a): blocks per episode) is returned through the pointer when it is not null.
+int denet_classify_fwd_layout(int64_t N, int64_t K, int64_t P, int64_t* groups_out) {
+    const int RT = (int)((K + 31) / 32);
+    // K <= 32 with many tiles: layout (b) (a wave per tile, Wn staged once per four tiles) instead of the
+    // latency-oriented eight-waves-per-tile kernel
+    // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
+    const bool wide1 = RT == 1 && N * ((P + CL_TP - 1) / CL_TP) >= 384;
+    if (RT < 2 && !wide1) return DENET_CLS_TILE8;
+    // K > 32: Wn[n] resident in LDS.  Two layouts: (a) units of (32-position half tile, 32-row tile) dealt to
+    // 8 waves, N x groups ~ 256 blocks -- a SIMD carries ceil(units / 4) x 128 MFMAs; (b) a wave per 64-position
+    // tile and four tiles per block -- 768 MFMAs per SIMD at RT = 3, but every Fq element loaded once, 8 bytes
+    // per lane (layout (a) reads it RT times, 4 bytes per lane).  (a) where it takes the matrix work per SIMD
+    // to two thirds or less (C3: 512 against 768, F3 46 -> 39 us), (b) otherwise (C5: 768 either way, and
+    // (a) measured 51 us against 48).
+    const int64_t nht = (P + 31) / 32;
+    int64_t groups = 256 / N;
+    if (groups > nht) groups = nht;
+    if (groups < (nht + CLW_MAXH - 1) / CLW_MAXH) groups = (nht + CLW_MAXH - 1) / CLW_MAXH;
+    if (groups_out) *groups_out = groups;
+    const int64_t units = ((nht + groups - 1) / groups) * RT;
+    const bool by_units = !wide1 && ((units + 3) / 4) * 128 * 3 <= (int64_t)RT * 256 * 2;
+    return by_units ? DENET_CLS_UNITS : DENET_CLS_WAVE4;
+}
+
 template <typename T, bool BUILD = false>
 static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, const int64_t* labels, int64_t N,
                                int64_t way, int64_t K, int64_t C, int64_t P, int base, float* logits, float* bin,
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
-    // K <= 32 with many tiles: layout (b) below (a wave per tile, Wn staged once per four tiles) instead of the
-    // latency-oriented eight-waves-per-tile kernel
-    // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
-    const bool wide1 = RT == 1 && N * ((P + CL_TP - 1) / CL_TP) >= 384;
-    if (RT >= 2 || wide1) {
-        // K > 32: Wn[n] resident in LDS.  Two layouts: (a) units of (32-position half tile, 32-row tile) dealt to
-        // 8 waves, N x groups ~ 256 blocks -- a SIMD carries ceil(units / 4) x 128 MFMAs; (b) a wave per 64-position
-        // tile and four tiles per block -- 768 MFMAs per SIMD at RT = 3, but every Fq element loaded once, 8 bytes
-        // per lane (layout (a) reads it RT times, 4 bytes per lane).  (a) where it takes the matrix work per SIMD
-        // to two thirds or less (C3: 512 against 768, F3 46 -> 39 us), (b) otherwise (C5: 768 either way, and
-        // (a) measured 51 us against 48).
-        const int64_t nht = (P + 31) / 32;
-        int64_t groups = 256 / N;
-        if (groups > nht) groups = nht;
-        if (groups < (nht + CLW_MAXH - 1) / CLW_MAXH) groups = (nht + CLW_MAXH - 1) / CLW_MAXH;
-        const int64_t units = ((nht + groups - 1) / groups) * RT;
-        const bool by_units = !wide1 && ((units + 3) / 4) * 128 * 3 <= (int64_t)RT * 256 * 2;
+    int64_t groups = 0;
+    const int layout = denet_classify_fwd_layout(N, K, P, &groups);
+    if (layout != DENET_CLS_TILE8) {
+        const bool by_units = layout == DENET_CLS_UNITS;
         if (!by_units) {
             const size_t lds4 = (size_t)32 * RT * (C + 1) * 4;          // rows K .. 32*RT-1 are zero padding
             if (lds4 > 160 * 1024 || RT > 4) return DENET_E_UNSUPPORTED;

@@ -255,7 +255,9 @@ __device__ __forceinline__ void masked_sum_fwd_body(const T* __restrict__ Fs, co
         };
         const float* pb[V];
         plane_bases(head, pb);
-        // (i up to nvec + 959 is read: the image's tail; the select discards it)
+        // (vector i up to nvec + 959 is read and discarded by the select: one float per plane in a planar image,
+        // i.e. inside its MASK_TAIL; V floats per vector in the row-major fp32 image, where those reads fall into
+        // the parked W1 slices or the padding launch_pool allocates behind the image)
         auto eat = [&](int i0, int off, const vec_t (&vv)[NV]) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {

@@ -119,13 +119,27 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
 #ifndef DENET_DFS_NT_MB
 #define DENET_DFS_NT_MB 80          // dFs streams above this size leave with non-temporal stores (see B3 below)
 #endif
+#ifndef DENET_DFQ_NT_MB
+#define DENET_DFQ_NT_MB 80          // dFq streams UP TO this size leave B1 with non-temporal stores (dev_classify.hpp, NTQ)
+#endif
+// the backward launchers' choices, from the call's sizes alone (also reported by denet_head_step_plan)
+static inline bool bwd_persistent(int64_t P) { return P >= 4; }       // quad loads need P >= 4
+static inline bool bwd_dfq_nt(int64_t N, int64_t C, int64_t P, size_t sF) {
+    return N * C * P * (int64_t)sF <= ((int64_t)DENET_DFQ_NT_MB << 20);
+}
+// dFs streams go around the caches (dev_masked_sum.hpp, NT) unless the whole step's working set stays
+// resident in the 256 MB last-level cache.  Measured (C2 shape, fp32, step time cached vs NT): 69 MB
+// 86.9 vs 90.7 us, 103 MB 127.8 vs 125.3, 138 MB 161.5 vs 144.2, 207 MB 221.6 vs 204.9, 275 MB 287.1 vs
+// 260.1; bf16 at C5's shape: 67 MB 158.7 vs 156.4, 134 MB 250.1 vs 238.0, 269 MB 427.1 vs 418.6.
+static inline bool dfs_nt(int64_t B, int64_t C, int64_t P, size_t sF) {
+    return B * C * P * (int64_t)sF > ((int64_t)DENET_DFS_NT_MB << 20);
+}
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
     if (wide) {                         // persistent blocks (quad loads need P >= 4; see cls_bwd_parts below)
         const size_t ldw = CLW_BWD_LDS(RT);
-        // dFq streams up to 80 MB leave with non-temporal stores (dev_classify.hpp, NTQ)
-        if ((int64_t)N * g.C * g.P * (int64_t)sizeof(T) <= ((int64_t)80 << 20)) {
+        if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
             if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT, true>), ldw))
                 return DENET_E_LAUNCH;
             hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
@@ -202,6 +216,39 @@ extern "C" int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t sho
     const int64_t pk = denet_upsample_loss_parts(K, h, w, H, W, 1), pp = denet_upsample_loss_parts(2, h, w, H, W, 0);
     if (pk < 0 || pp < 0) return DENET_E_UNSUPPORTED;
     return carve(nullptr, N, way, shot, K, C, h, w, pk, pp).total;
+}
+
+extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                                    int64_t H, int64_t W, int feat_dtype, denet_step_plan_t* out) {
+    if (!out) return DENET_E_BADARG;
+    if (N <= 0 || way <= 0 || shot <= 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return DENET_E_BADARG;
+    if (!(C == 64 || C == 256) || K > 128 || shot > 8) return DENET_E_UNSUPPORTED;
+    if (feat_dtype != DENET_F32 && feat_dtype != DENET_BF16) return DENET_E_UNSUPPORTED;
+    const int64_t B = N * way * shot, P = h * w;
+    const size_t sF = feat_dtype == DENET_F32 ? 4 : 2;
+    const int RT = (int)((K + 31) / 32);
+    denet_step_plan_t p{};
+    const PoolPlan pl = denet_pool_plan(feat_dtype, B, C, P, true);
+    p.pool_launches = pl.two_launch ? 2 : 1;
+    p.pool_long_rows = pl.long_rows;
+    p.pool_nt_loads = pl.nt_loads;
+    int64_t groups = 0;
+    p.classify_layout = denet_classify_fwd_layout(N, K, P, &groups);
+    p.classify_groups = p.classify_layout == DENET_CLS_UNITS ? (int32_t)groups : 0;
+    LossPlan lp;
+    if (!denet_loss_plan(K, h, w, H, W, true, &lp)) return DENET_E_UNSUPPORTED;
+    p.loss_chain_cell = lp.chain_cell;
+    p.loss_chunk = lp.chunk;
+    p.loss_xsplit = lp.xsplit;
+    p.bwd_persistent = bwd_persistent(P);
+    p.bwd_groups = p.bwd_persistent ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
+    p.bwd_dfq_nt = p.bwd_persistent && bwd_dfq_nt(N, C, P, sF);
+    p.dfs_nt = dfs_nt(B, C, P, sF);
+    // (dev_masked_sum.hpp, masked_sum_bwd_body: ROWS = !NT || bf16)
+    p.dfs_flat_writer = p.dfs_nt && !(sF == 2 && DENET_NT_BF16_ROWS);
+    *out = p;
+    return DENET_OK;
 }
 
 #define TRY(x)                 \
@@ -330,7 +377,7 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
     // persistent blocks at every K (quad loads need P >= 4).  K <= 32 against one tile per block: C2 step
     // 88.2 vs 89.7 us at 8 episodes (14 slabs per episode instead of 27 for B2 to sum), 1.000 vs 1.024 ms at 128
     // (B2 18 vs 57 us)
-    const bool wide = P >= 4;
+    const bool wide = bwd_persistent(P);
     const int n_part = wide ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
     const bool f32 = feat_dtype == DENET_F32;
     hipStream_t st = (hipStream_t)stream;
@@ -380,11 +427,7 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        // dFs streams go around the caches (dev_masked_sum.hpp, NT) unless the whole step's working set stays
-        // resident in the 256 MB last-level cache.  Measured (C2 shape, fp32, step time cached vs NT): 69 MB
-        // 86.9 vs 90.7 us, 103 MB 127.8 vs 125.3, 138 MB 161.5 vs 144.2, 207 MB 221.6 vs 204.9, 275 MB 287.1 vs
-        // 260.1; bf16 at C5's shape: 67 MB 158.7 vs 156.4, 134 MB 250.1 vs 238.0, 269 MB 427.1 vs 418.6.
-        const bool nt = B * C * P * (f32 ? 4 : 2) > ((int64_t)DENET_DFS_NT_MB << 20);
+        const bool nt = dfs_nt(B, C, P, f32 ? 4 : 2);
         // LDS: the mask image of the dFs blocks (dev_masked_sum.hpp) + their 64 + 16 floats
         size_t lds = (size_t)((f32 ? (nt ? mask_image_floats<4, MaskImage<float, true>::PLANAR>((int)P)
                                          : mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P))

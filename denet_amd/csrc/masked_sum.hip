@@ -105,15 +105,40 @@ extern "C" int denet_mask_resize(const int64_t* Ys, int64_t B, int64_t H, int64_
 #endif
 static inline int pick_rows_per_block(int64_t C) { return C >= DENET_RPB ? DENET_RPB : (int)C; }
 
+// The launcher's choices for the pooling stage, from the call's sizes alone (also reported by
+// denet_head_step_plan, so that tests can tell which variant a shape runs).
+PoolPlan denet_pool_plan(int feat_dtype, int64_t B, int64_t C, int64_t P, bool fused) {
+    const bool f32 = feat_dtype == DENET_F32;
+    const int rpb = pick_rows_per_block(C);
+    const int64_t nblk = ((C + rpb - 1) / rpb) * B;
+    PoolPlan pl;
+    // in the fused step the mask is resized in a launch of its own from 64 images or 64 x 64 features on
+    // (denet_masked_pool_fwd_chain below)
+    pl.two_launch = fused && (P >= 4096 || B >= 64);
+    // short rows (up to 512 16-byte vectors: whole rows in flight) or long rows (rolling loop)
+    pl.long_rows = P / (f32 ? 4 : 8) > 512;
+    // feature streams of more than 160 MB are read around the caches (dev_masked_sum.hpp, NTL).  Step time
+    // without / with, C2's shape: 138 MB 144.2 / 147.1 us, 172 MB 175.7 / 172.9, 207 MB 204.6 / 192.6, 241 MB
+    // 243.6 / 228.9; C5's shape (bf16): 134 MB 237.1 / 237.0, 202 MB 332.9 / 316.1, 269 MB 420.5 / 397.9
+    pl.nt_loads = nblk * rpb * P * (f32 ? 4 : 2) > ((int64_t)160 << 20);
+    return pl;
+}
+
 // the pooling kernel: short rows (up to 512 16-byte vectors: whole rows in flight) or long rows (rolling loop)
 static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float* mask, float* cnt, float* S, int C, int P,
                        int rpb, int H, int W, int h, int w, const float* W1, float* pre1_part, dim3 grid, hipStream_t st) {
     const bool f32 = feat_dtype == DENET_F32;
-    const bool longr = P / (f32 ? 4 : 8) > 512;
-    // LDS: the planar mask image (dev_masked_sum.hpp) + 4 + 16 floats (+ the parked W1 slices)
+    const PoolPlan pl = denet_pool_plan(feat_dtype, (int64_t)grid.x / ((C + rpb - 1) / rpb), C, P, false);
+    const bool longr = pl.long_rows;
+    // LDS: the mask image (dev_masked_sum.hpp) + 4 + 16 floats (+ the parked W1 slices).  The long-row loop reads
+    // the image up to 959 vectors past the row's end (discarded by a select): a planar image holds one float per
+    // vector and plane, so its MASK_TAIL covers that; the row-major fp32 image holds four, and those reads land
+    // in the parked W1 slices -- or, without them (stand-alone call), in 3072 floats of padding
+    const bool rowmajor = f32 && longr && !MaskImage<float, false>::PLANAR;
     const size_t lds = (size_t)((f32 ? (longr ? mask_image_floats<4, MaskImage<float, false>::PLANAR>(P)
                                           : mask_image_floats<4, MaskImage<float, true>::PLANAR>(P))
-                                   : mask_image_floats<8, true>(P)) + 4 + 16) * 4 + (W1 ? 256 * 64 : 0);
+                                   : mask_image_floats<8, true>(P)) + 4 + 16) * 4 +
+                       (W1 ? 256 * 64 : (rowmajor ? 3072 * 4 : 0));
 #define POOL_GO2(TT, LG, NL)                                                                                      \
     do {                                                                                                          \
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(masked_sum_fwd_kernel<TT, LG, NL>), lds))      \
@@ -125,10 +150,7 @@ static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float*
     do {                                                                                                          \
         if (ntl) POOL_GO2(TT, LG, true); else POOL_GO2(TT, LG, false);                                            \
     } while (0)
-    // feature streams of more than 160 MB are read around the caches (dev_masked_sum.hpp, NTL).  Step time
-    // without / with, C2's shape: 138 MB 144.2 / 147.1 us, 172 MB 175.7 / 172.9, 207 MB 204.6 / 192.6, 241 MB
-    // 243.6 / 228.9; C5's shape (bf16): 134 MB 237.1 / 237.0, 202 MB 332.9 / 316.1, 269 MB 420.5 / 397.9
-    const bool ntl = (int64_t)grid.x * rpb * P * (f32 ? 4 : 2) > ((int64_t)160 << 20);
+    const bool ntl = pl.nt_loads;
     if (f32) {
         if (longr) POOL_GO(float, true); else POOL_GO(float, false);
     } else {
@@ -205,7 +227,7 @@ int denet_masked_pool_fwd_chain(const void* Fs, int feat_dtype, const int64_t* Y
     // costs the stream 15 us of 86 at 200 images (C3) and 40 of 258 at 640 (scripts/diag/pool_stamps: modes
     // 1 / 0 / 2); the extra launch costs ~4 us, which only small batches cannot afford (C2 step: 88.7 vs 87.2 us
     // at 40 images, 160.5 vs 161.7 us at 80).
-    if (P >= 4096 || B >= 64) {
+    if (denet_pool_plan(feat_dtype, B, C, P, true).two_launch) {
         if (!fits_int(B * P)) return DENET_E_UNSUPPORTED;
         const int total = (int)(B * P);
         hipLaunchKernelGGL(mask_resize_flat_kernel, dim3((unsigned)((total + 256 * MRF_E - 1) / (256 * MRF_E))), dim3(256),

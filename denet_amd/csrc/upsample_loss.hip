@@ -191,6 +191,13 @@ static bool loss_geom(int K, int h, int w, int H, int W, bool grad, LossGeom* g)
     return true;
 }
 
+bool denet_loss_plan(int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, bool grad, LossPlan* out) {
+    LossGeom g;
+    if (!loss_geom((int)K, (int)h, (int)w, (int)H, (int)W, grad, &g)) return false;
+    *out = LossPlan{g.em, g.em ? g.kchunk : 0, g.xsplit, g.rsplit};
+    return true;
+}
+
 extern "C" int64_t denet_upsample_loss_parts(int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, int with_grad) {
     if (K <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DENET_E_BADARG;
     LossGeom g;

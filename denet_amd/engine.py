@@ -48,7 +48,6 @@ class HeadStepEngine:
         self._deferred = False
         self._have_focal = True
         self._bound = None
-        self._bound_args = None
 
     def set_probe(self, which, start_event, stop_event):
         """Bracket kernel `which` (a name in _lib.KERNEL_IDS, or None) with HIP events."""
@@ -70,13 +69,18 @@ class HeadStepEngine:
         then only make the library calls -- the argument conversion is done once here.  The tensors must
         stay alive and in place.  drop: a _lib.Dropout (train mode, masks generated in the kernels); the
         library reads it at every call, so advance `drop.seed` in place between steps."""
-        self._bound_args = (Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k, drop)
-        self._rebind()
+        self._bound = self.make_bound(Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask,
+                                      grad_loss_k, drop)
 
-    def _rebind(self):
-        if self._bound_args is None:
-            return
-        Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask, weight_mask, grad_loss_k, drop = self._bound_args
+    def use_bound(self, bound):
+        """Switch to another pre-bound argument set (make_bound): a loop that rotates over several resident
+        batches binds each once and switches between them with this field write."""
+        self._bound = bound
+
+    def make_bound(self, Fq, Fs, Ys, labels, Yq, Yq_full, wgt, params, gate_mask=None, weight_mask=None,
+                   grad_loss_k=None, drop=None):
+        """The pre-converted calls of one step on these input tensors (outputs, gradients and workspace are the
+        engine's own): what bind_step installs."""
         N, way, shot, K, C, h, w, H, W = self.dims
         P = [params[k] for k in PARAM_ORDER]
         deferred = Yq_full is not None
@@ -96,7 +100,7 @@ class HeadStepEngine:
                 g["gam.gate.0.bias"], g["gam.gate.2.weight"], g["gam.gate.2.bias"], g["map.linear.weight"],
                 g["map.linear.bias"], self.losses if deferred else None,
                 (_lib.BWD_HAVE_FOCAL if have_focal else 0) | fl, self.ws, self.ws_bytes, self._probe)
-        self._bound = (fwd, bwd, deferred, have_focal)
+        return (fwd, bwd, deferred, have_focal)
 
     def run_forward(self, stream=None):
         fwd, _, self._deferred, self._have_focal = self._bound

@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, sharding
 from .operations import depart_first_dim, merge_first_k_dim
 
 
@@ -120,7 +120,10 @@ class WeightEstimator(nn.Module):
         if not self.training:
             return None
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            # every rank of a torchrun job starts torch's generator from the same default seed, so the draw
+            # alone would give all shards bit-identical masks: draw * world + rank is distinct per rank and step
+            world, rank = sharding.world(), sharding.rank()
+            seed = int(torch.randint(0, 2 ** 62 // world, (1,), dtype=torch.int64).item()) * world + rank
         return seed, float(self.gam.gate[3].p), float(self.dropout.p)
 
     def _dropout_masks(self, B, N, device, seed=None):
@@ -220,11 +223,55 @@ class WeightEstimator(nn.Module):
         if self.sfree:
             full = self.infer(embedding, self.extend(Fs, Ys, labels), mode='training')
             return full, ops.binary_logits(full.detach(), labels, way=way, base=base)
+        need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (embedding, Fs) + self._params())
+        if not need_grad and base and self._fused_ok(Fs, Ys):
+            # forward only (test / inference loops): the fused step's three forward launches, dropout (train
+            # mode without gradients) generated in the kernels
+            drop = self.dropout_config() if gate_mask is None and weight_mask is None else None
+            if drop is None or max(drop[1:]) < 1.0:          # (p = 1 has no in-kernel form: masks of zeros below)
+                return ops.head_forward(embedding, Fs, self._params(), Ys, labels, gate_mask, weight_mask, drop)
         if gate_mask is None and weight_mask is None:
             gate_mask, weight_mask = self._dropout_masks(N * way * shot, N, Fs.device)
         full, binl, _ = ops.EstimatorFunction.apply(embedding, Fs, *self._params(), Ys, labels, gate_mask,
                                                     weight_mask, base)
         return full, binl
+
+    def _fused_ok(self, Fs, Ys):
+        """Whether the fused step's kernels take this shape (denet_head_step_workspace says so)."""
+        N, way, shot, C, h, w = Fs.shape
+        H, W = Ys.shape[-2:]
+        return C in (64, 256) and ops.query("denet_head_step_workspace", N, way, shot, self.num_classes, C, h, w,
+                                            H, W) > 0
+
+    def head_step(self, embedding, Fs, Ys, labels, Yq, Yq_full, weight=None, gate_mask=None, weight_mask=None):
+        """The reference's training-step sequence for the head -- estimator(...) + get_binary_logits
+        (model/head/denet.py:79-91), both F.interpolate calls (trainer/trainers.py:954-956) and
+        DENet_loss_wrapper (trainer/utils.py:264-281) -- as ONE autograd node on the fused seven-launch step
+        (ops.HeadStepFunction): returns (loss_k, loss_p, logits_full (N,K,h,w), logits_binary (N*way,2,h,w));
+        loss_k.backward() runs the three backward launches.  weight: (N,K) per-episode class weights of the
+        cross entropy (trainer/trainers.py:961-963) or None.  Train mode draws ONE dropout seed; the masks
+        are generated inside the kernels (and regenerated in the backward)."""
+        N, way, shot = Fs.shape[:3]
+        labels = self._labels2d(labels, N).to(Fs.device)
+        if self.sfree:
+            # support_free persists weights episode by episode (model/common.py:332-338): forward only,
+            # on the stand-alone kernels
+            from .losses import loss_denet_batch
+            full, binl = self.forward_with_binary(embedding, Fs, Ys, labels)
+            loss_k, loss_p = loss_denet_batch(full, Yq_full, binl, Yq, weight)
+            return loss_k, loss_p, full, binl
+        drop = None
+        if gate_mask is None and weight_mask is None:
+            drop = self.dropout_config()
+            if drop is not None and max(drop[1:]) >= 1.0:    # p = 1: everything dropped, as tensors of zeros
+                gate_mask, weight_mask = self._dropout_masks(N * way * shot, N, Fs.device, seed=drop[0])
+                drop = None
+            if drop is not None:
+                self.last_dropout_seed = drop[0]
+        wgt = None if weight is None else weight.to(Fs.device, torch.float32).reshape(N, self.num_classes).contiguous()
+        Yq2 = None if Yq is None else Yq.reshape(N * way, *Yq.shape[-2:])
+        return ops.HeadStepFunction.apply(embedding, Fs, *self._params(), Ys, labels, Yq2, Yq_full, wgt,
+                                          gate_mask, weight_mask, drop)
 
 
 # ------------------------------------------------------------------------------------------
@@ -351,6 +398,22 @@ class DENet(nn.Module):
         # knowledge logits and, per way, the pattern (binary) logits: one fused node
         logits_full, logits_binary = self.estimator.forward_with_binary(Fq, Fs, Ys, label)
         return logits_full, logits_binary
+
+    def forward_step(self, Is, Ys, Iq, label, Yq, Yq_full, weight=None):
+        """forward() + the two up-samplings + DENet_loss_wrapper of the reference's training step
+        (trainer/trainers.py:951-968) in one call: (loss_k, loss_p, logits_full, logits_binary).  The head
+        part is ONE fused autograd node (WeightEstimator.head_step); `loss_k.backward()` then reaches the
+        conv stack through dFq / dFs.  forward() stays what inference calls."""
+        N, way, shot = Is.size()[:3]
+        Fs = self.features(merge_first_k_dim(Is, dims=(0, 1, 2)))
+        Fs = depart_first_dim(Fs, dims=(N * way, shot))
+        if self.visualize and way == 1:
+            self.vis.update({'hidden_Fs': torch.select(Fs, dim=1, index=0).clone().detach()})
+        Fs = depart_first_dim(Fs, dims=(N, way))
+        Fq = self.features(Iq)
+        if self.visualize:
+            self.vis.update({'hidden_Fq': Fq.clone().detach()})
+        return self.estimator.head_step(Fq, Fs, Ys, label, Yq, Yq_full, weight)
 
 
 key2arch = {'DENet': DENet}

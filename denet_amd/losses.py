@@ -34,30 +34,56 @@ def _match_sizes(input, target):
     return input, target
 
 
+def _remap_ignore(target, ignore_index):
+    """The kernels narrow labels to bytes and treat 255 as "ignore" (the reference's default and only value,
+    loss/losses.py:19,47).  Any other ignore_index is mapped onto 255 first; class ids are < K <= 128, so 255
+    never names a class."""
+    if ignore_index == ops.IGNORE_INDEX:
+        return target
+    return torch.where(target == ignore_index, torch.full_like(target, ops.IGNORE_INDEX), target)
+
+
+def _check_reduction(reduction):
+    if reduction not in ('mean', 'sum', 'none'):
+        raise ValueError("{} is not a valid value for reduction".format(reduction))
+
+
 def cross_entropy2d(input, target, weight=None, ignore_index=255, reduction='mean'):
-    """loss/losses.py:19-44."""
-    if ignore_index != ops.IGNORE_INDEX:
-        raise NotImplementedError("the HIP kernel fixes ignore_index=255 (the only value the reference uses)")
-    if reduction != 'mean':
-        raise NotImplementedError("only reduction='mean' (the only value the reference uses)")
+    """loss/losses.py:19-44.  'mean' and 'sum' run the fused up-sampling + CE kernel; 'none' (a per-pixel map,
+    which no caller in the reference asks for) materialises the up-sampled logits with stock device ops."""
+    _check_reduction(reduction)
     input, target = _match_sizes(input, target)
     n, c = input.shape[:2]
+    if reduction == 'none':
+        if input.shape[-2:] != target.shape[-2:]:
+            input = F.interpolate(input, size=target.shape[-2:], mode="bilinear", align_corners=True)
+        flat = input.permute(0, 2, 3, 1).contiguous().view(-1, c)
+        w = None if weight is None else weight.to(input.device, input.dtype)
+        return F.cross_entropy(flat, target.reshape(-1), weight=w, ignore_index=ignore_index, reduction='none')
     wgt = None
     if weight is not None:
         wgt = weight.to(input.device, torch.float32).reshape(1, c).expand(n, c).contiguous()
-    return ops.UpsampleWCEFunction.apply(input.float(), target.long(), wgt, True)
+    return ops.UpsampleWCEFunction.apply(input.float(), _remap_ignore(target.long(), ignore_index), wgt, True,
+                                         reduction)
 
 
 def binary_focal_loss(input, target, alpha=0.25, gamma=2, ignore_index=255, reduction='mean'):
-    """loss/losses.py:47-79 (forward only, like every use of it in the reference)."""
-    if ignore_index != ops.IGNORE_INDEX:
-        raise NotImplementedError("the HIP kernel fixes ignore_index=255 (the only value the reference uses)")
-    if reduction != 'mean':
-        raise NotImplementedError("only reduction='mean' (the only value the reference uses)")
+    """loss/losses.py:47-79 (forward only on the fused kernel, like every use of it in the reference;
+    reduction='none' goes through stock device ops and is differentiable)."""
+    _check_reduction(reduction)
     input, target = _match_sizes(input, target)
     if input.shape[1] != 2:
         raise ValueError("binary_focal_loss expects 2 channels, got %d" % input.shape[1])
-    return ops.UpsampleFocalFunction.apply(input.float(), target.long(), float(alpha), float(gamma))
+    if reduction == 'none':
+        if input.shape[-2:] != target.shape[-2:]:
+            input = F.interpolate(input, size=target.shape[-2:], mode="bilinear", align_corners=True)
+        flat = input.permute(0, 2, 3, 1).contiguous().view(-1, 2)
+        probs = F.softmax(flat, dim=-1)
+        w = torch.tensor([alpha, 1 - alpha], device=input.device, dtype=flat.dtype)
+        return F.nll_loss((1 - probs) ** gamma * torch.log(probs), target.reshape(-1), weight=w,
+                          ignore_index=ignore_index, reduction='none')
+    return ops.UpsampleFocalFunction.apply(input.float(), _remap_ignore(target.long(), ignore_index), float(alpha),
+                                           float(gamma), reduction)
 
 
 def loss_general(input, target):

@@ -156,8 +156,9 @@ def classify_bwd(Fq, Wn, dlog_a, dlog_b=None, scale=None, gmul=None, need_dFq=Tr
 # --------------------------------------------------------------------------
 # K4 / K5
 # --------------------------------------------------------------------------
-def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False):
-    """-> (loss scalar tensor, per_episode [N], scale [N], dlog_a, dlog_b)."""
+def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False, reduction='mean'):
+    """-> (loss scalar tensor, per_episode [N], scale [N], dlog_a, dlog_b).  reduction='sum': the loss is the
+    weighted numerator summed over the batch and `scale` is None (the slabs are its gradient as they stand)."""
     logits = logits.contiguous()
     N, K, h, w = logits.shape
     Y = _as_i64(Yq_full).contiguous().reshape(N, *Yq_full.shape[-2:])
@@ -170,6 +171,8 @@ def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False):
     da = torch.empty_like(logits) if grad else None
     db = torch.empty_like(logits) if grad else None
     call("denet_upsample_wce_fwd", logits, Y, wgt, N, K, h, w, H, W, part, da, db)
+    if reduction == 'sum':
+        return part[:, :, 0].double().sum().float(), None, None, da, db
     out = _f32(2, device=dev)
     per = _f32(N, device=dev)
     scale = _f32(N, device=dev)
@@ -177,7 +180,7 @@ def upsample_wce(logits, Yq_full, wgt=None, grad=False, pooled=False):
     return out[0], per, scale, da, db
 
 
-def upsample_focal(logits_binary, Yq, alpha=0.25, gamma=2.0):
+def upsample_focal(logits_binary, Yq, alpha=0.25, gamma=2.0, reduction='mean'):
     lb = logits_binary.contiguous()
     NB, two, h, w = lb.shape
     assert two == 2
@@ -188,6 +191,8 @@ def upsample_focal(logits_binary, Yq, alpha=0.25, gamma=2.0):
         raise _lib.DenetHipError(f"denet_upsample_loss_parts: {_lib.strerror(parts)}")
     part = _f32(NB, parts, 2, device=lb.device)
     call("denet_upsample_focal_fwd", lb, Y, NB, h, w, H, W, alpha, gamma, part)
+    if reduction == 'sum':
+        return part[:, :, 0].double().sum().float()
     out = _f32(2, device=lb.device)
     call("denet_loss_finalize", None, part, 0, NB, 0, parts, 0, out, None, None)
     return out[1]
@@ -403,26 +408,28 @@ class UpsampleWCEFunction(torch.autograd.Function):
     (trainer/utils.py:270-277)."""
 
     @staticmethod
-    def forward(ctx, logits, target, wgt, pooled):
+    def forward(ctx, logits, target, wgt, pooled, reduction='mean'):
         need = logits.requires_grad
-        loss, per, scale, da, db = upsample_wce(logits, target, wgt, grad=need, pooled=pooled)
+        loss, per, scale, da, db = upsample_wce(logits, target, wgt, grad=need, pooled=pooled, reduction=reduction)
         if need:
-            ctx.save_for_backward(scale, da, db)
+            ctx.has_scale = scale is not None
+            ctx.save_for_backward(*((scale,) if scale is not None else ()), da, db)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        scale, da, db = ctx.saved_tensors
+        sv = ctx.saved_tensors
+        scale, (da, db) = (sv[0] if ctx.has_scale else None), sv[-2:]
         g = gout.contiguous().float().reshape(1)
-        return combine_slabs(da, db, scale, g), None, None, None
+        return combine_slabs(da, db, scale, g), None, None, None, None
 
 
 class UpsampleFocalFunction(torch.autograd.Function):
     """binary_focal_loss with the up-sampling fused in (loss/losses.py:47-79); forward only."""
 
     @staticmethod
-    def forward(ctx, logits_binary, target, alpha, gamma):
-        return upsample_focal(logits_binary, target, alpha, gamma)
+    def forward(ctx, logits_binary, target, alpha, gamma, reduction='mean'):
+        return upsample_focal(logits_binary, target, alpha, gamma, reduction)
 
     @staticmethod
     def backward(ctx, gout):
@@ -433,10 +440,42 @@ class UpsampleFocalFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------
 # autograd: the fused head step (T1)
 # --------------------------------------------------------------------------
+class _WorkspacePool:
+    """Step workspaces by (device, stream, bytes): the fused step's scratch slab (~150 MB at C2) is handed from
+    one step to the next instead of going through the allocator on every call.  A forward takes a slab, the
+    matching backward (or a forward that needs no gradient) puts it back; everything is enqueued on one stream,
+    so the next step's kernels are ordered behind the last reader.  A graph that is dropped without a backward
+    simply frees its slab."""
+
+    def __init__(self):
+        self._free = {}
+
+    def take(self, nbytes, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, int(nbytes))
+        free = self._free.get(key)
+        if free:
+            return key, free.pop()
+        return key, torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def give(self, key, ws):
+        free = self._free.setdefault(key, [])
+        if len(free) < 2:
+            free.append(ws)
+
+    def clear(self):
+        self._free.clear()
+
+
+workspace_pool = _WorkspacePool()
+
+
 class HeadStepFunction(torch.autograd.Function):
     """One call for forward + both losses; backward runs K3b/K2b/K1b from the
     gradient slabs the forward already wrote.  Returns
-    (loss_k, loss_p, logits_full, logits_binary); only loss_k is differentiable."""
+    (loss_k, loss_p, logits_full, logits_binary); only loss_k is differentiable.
+    This is the node behind WeightEstimator.head_step / DENet.forward_step / DENetTrainer.step, i.e. the
+    reference's model(...) -> F.interpolate x2 -> loss_func -> loss_k.backward() sequence
+    (trainer/trainers.py:951-975) as seven launches."""
 
     @staticmethod
     def forward(ctx, Fq, Fs, weight, W1, b1, W2, b2, Wl, bl, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask,
@@ -454,11 +493,11 @@ class HeadStepFunction(torch.autograd.Function):
         H, W = Ys.shape[-2:]
         Yq = _as_i64(Yq).contiguous() if Yq is not None else None
         Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
-        need = any(t.requires_grad for t in (Fq, Fs) + params)
+        need = any(ctx.needs_input_grad[:9])          # (false under no_grad as well: validation steps)
         nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
         if nbytes < 0:
             raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(nbytes)}")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws_key, ws = workspace_pool.take(nbytes, dev)
         logits = _f32(N, K, h, w, device=dev)
         binl = _f32(N * way, 2, h, w, device=dev)
         losses = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -467,7 +506,11 @@ class HeadStepFunction(torch.autograd.Function):
              ws, nbytes, None)
         ctx.dims = (N, way, shot, K, C, h, w, H, W)
         ctx.have_focal = Yq is not None
-        ctx.ws = ws
+        if need:
+            ctx.ws, ctx.ws_key = ws, ws_key
+        else:
+            ctx.ws = None
+            workspace_pool.give(ws_key, ws)          # nothing will read it again
         ctx.fs_shape = Fs.shape
         ctx.save_for_backward(Fq, labels, params[1], params[3], params[5],
                               *(t for t in (gate_mask, weight_mask) if t is not None))
@@ -481,6 +524,9 @@ class HeadStepFunction(torch.autograd.Function):
     def backward(ctx, g_k, g_p, g_l, g_b):
         if g_k is None:
             return (None,) * 17
+        if ctx.ws is None:
+            raise RuntimeError("HeadStepFunction: the step's workspace went back to the pool after the first "
+                               "backward; a second backward through the same step is not supported")
         N, way, shot, K, C, h, w, H, W = ctx.dims
         sv = list(ctx.saved_tensors)
         Fq, labels, W1, W2, Wl = sv[:5]
@@ -498,7 +544,36 @@ class HeadStepFunction(torch.autograd.Function):
              ctx.drop, g,
              N, way, shot, K, C, h, w, H, W, dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl, None,
              1 if ctx.have_focal else 0, ctx.ws, ctx.ws.numel(), None)
+        workspace_pool.give(ctx.ws_key, ctx.ws)
+        ctx.ws = None
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 8
+
+
+def head_forward(Fq, Fs, params, Ys, labels, gate_mask=None, weight_mask=None, drop=None):
+    """Forward only, no losses: K0..K3e through the fused step's three forward launches (F1 pooling + split-K,
+    F2 gate / projection, F3 Wn assembly + classifier + binary logits) instead of the stand-alone kernel chain.
+    What WeightEstimator.forward_with_binary runs when no gradient is asked for (test / inference loops,
+    trainer/trainers.py:1110-1141).  params = (weight, W1, b1, W2, b2, Wl, bl).  -> (logits_full, logits_binary)."""
+    N, way, shot, C, h, w = Fs.shape
+    K = params[0].shape[0]
+    dev = Fq.device
+    Fq, Fs = Fq.contiguous(), Fs.contiguous()
+    params = tuple(t.detach().contiguous() for t in params)
+    labels = _as_i64(labels).contiguous()
+    Ys = _as_i64(Ys).contiguous()
+    H, W = Ys.shape[-2:]
+    nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
+    if nbytes < 0:
+        raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(nbytes)}")
+    ws_key, ws = workspace_pool.take(nbytes, dev)
+    logits = _f32(N, K, h, w, device=dev)
+    binl = _f32(N * way, 2, h, w, device=dev)
+    losses = _f32(2, device=dev)
+    call("denet_head_step_train_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, None, None, None, *params,
+         gate_mask, weight_mask, _lib.Dropout(*drop) if drop is not None else None, N, way, shot, K, C, h, w, H, W,
+         0, logits, binl, losses, ws, nbytes, None)
+    workspace_pool.give(ws_key, ws)
+    return logits, binl
 
 
 def dropout_mask(seed, stream_id, p, shape, device):

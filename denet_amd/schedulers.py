@@ -10,6 +10,7 @@ reference defines itself; they are expressed as ``LambdaLR`` factors with the re
 from __future__ import annotations
 
 import functools
+import warnings
 
 from torch.optim import lr_scheduler as _S
 
@@ -54,3 +55,13 @@ def get_scheduler(optimizer, scheduler_dict):
         raise NotImplementedError('Scheduler {} not implemented'.format(s_type))
     print('Using scheduler: {} with {} params'.format(s_type, params))
     return key2scheduler[s_type](optimizer, **params)
+
+
+def tick(scheduler, epoch):
+    """The reference's per-epoch tick, ``scheduler.step(epoch=epoch_idx)`` (trainer/trainers.py:209): the rate is a
+    closed-form function of the epoch number, so a run resumed in epoch e (checkpoint: last_epoch = e, fresh
+    optimizer -- the reference does not restore it either, trainer/trainers.py:185-195) continues with epoch e's
+    rate instead of ticking one epoch ahead.  torch keeps this form of ``step`` behind a deprecation warning."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scheduler.step(epoch)

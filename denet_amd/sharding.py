@@ -95,3 +95,25 @@ class GradBucket:
         if w > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(w)
+
+
+def sync_buffers(module, group=None):
+    """Make the module's buffers identical on every rank: floating-point ones (BatchNorm running_mean /
+    running_var, which every rank updated from its own shard's statistics) become the mean over ranks,
+    integer ones (num_batches_tracked) are taken from rank 0.  Called before validation and checkpoints, so
+    that every rank evaluates -- and rank 0 saves -- ONE model instead of rank 0's shard-local statistics.
+    One flat all-reduce for the float buffers."""
+    if world() == 1:
+        return
+    fl = [b for b in module.buffers() if b.is_floating_point()]
+    if fl:
+        flat = torch.cat([b.detach().reshape(-1).float() for b in fl])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world())
+        off = 0
+        for b in fl:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    for b in module.buffers():
+        if not b.is_floating_point():
+            dist.broadcast(b, src=0, group=group)

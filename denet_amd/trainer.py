@@ -24,8 +24,10 @@ must be multiples of the world size: `loss_k` is a mean over the local episodes,
 the averaged gradient the gradient of the global batch); gradients are averaged with one flat all-reduce
 per step and the metric counts are summed once at the end (denet_amd/sharding.py).  The running B-IOU /
 F-IOU that train() prints every `log_steps` are rank 0's shard only (labelled so); train_val() / test()
-print all-reduced values.  BatchNorm statistics of the conv stack are per shard (no SyncBN): rank 0's
-running buffers are the ones a checkpoint keeps.
+print all-reduced values.  BatchNorm of the conv stack normalises with per-shard batch statistics unless
+`train.sync_bn: true` converts it to SyncBatchNorm; either way the running buffers are averaged over the
+ranks before every validation pass and checkpoint (sharding.sync_buffers), so all ranks evaluate, and rank 0
+saves, one model.
 """
 from __future__ import annotations
 
@@ -44,7 +46,7 @@ from . import ops, sharding
 from .head import DENet, freeze_weights, get_architecture, key2arch
 from .losses import get_loss, loss_denet_batch
 from .metrics import BinaryIOU as bIOU, FullIOU as fIOU
-from .schedulers import get_scheduler
+from .schedulers import get_scheduler, tick
 from .synthetic import EpisodeShape, make_episodes
 
 
@@ -140,6 +142,10 @@ def DENet_loss_wrapper(loss_func, arch):
     base = loss_func.func if isinstance(loss_func, functools.partial) else loss_func
     extra = loss_func.keywords if isinstance(loss_func, functools.partial) else {}
 
+    # the package's own loss_denet with the reference's defaults: DENetTrainer.step may then run forward +
+    # up-sampling + this wrapper as the fused head step (same arithmetic, one autograd node)
+    fusable = base is loss_denet and not extra
+
     @functools.wraps(base)
     def wrapper(*args, **kwargs):
         if arch not in ['DENet']:
@@ -155,6 +161,7 @@ def DENet_loss_wrapper(loss_func, arch):
         loss_p = loss_func(Yq_pre, Yq, mode='pattern')
         return loss_k, loss_p
 
+    wrapper.fused_head_step = fusable
     return wrapper
 
 
@@ -225,6 +232,8 @@ class DENetTrainer(object):
             self.train_cfg = train_config['train']
             self.testing = False
             self.way = 1                                   # training is 1-way only (dataset/voc_sbd.py:286-287)
+            if self.world > 1 and self.train_cfg.get('sync_bn', False):
+                self.model = nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
             opt = deepcopy(self.train_cfg['optimizer'])
             self.optimizer = _make_optimizer(opt.pop('name'), [p for p in self.model.parameters() if p.requires_grad],
                                              **opt)
@@ -247,6 +256,10 @@ class DENetTrainer(object):
             self.b_iou, self.f_iou = bIOU(), fIOU(num_classes=self.max_num_classes)
             self.meters = {k: AverageMeter() for k in ('loss', 'loss_k', 'loss_p')}
             self.logdir = self.train_cfg.get('logdir')
+            if self.train_cfg.get('resume'):
+                # continue a run from its latest / best checkpoint (trainer/trainers.py:71-80,185-195: model and
+                # scheduler are restored, the optimizer is not)
+                self._load_checkpoints(self.train_cfg['resume'], is_testing=False)
         else:
             self.test_cfg = test_config['test']
             self.testing = True
@@ -287,8 +300,18 @@ class DENetTrainer(object):
         self.model.train() if train else self.model.eval()
         data = sharding.shard_batch(tuple(data), self.rank, self.world)
         Is, Ys, Iq, Yq, cls_idx, Ys_full, Yq_full = [t.to(self.dev, non_blocking=True) for t in data]
-        Yq_pre, Ys_pre, Yq_full_pre, Ys_full_pre = DENet_forward_wrapper(
-            self.model, self.model_cfg['arch'], Is, Ys, Iq, Yq, cls_idx, Ys_full, Yq_full)
+        fused = not self.testing and getattr(self.loss_func, 'fused_head_step', False)
+        if fused:
+            # model(...) -> two F.interpolate -> loss_func (trainer/trainers.py:951-968) as one call: the conv
+            # stack, then ONE fused head node (DENet.forward_step -> ops.HeadStepFunction, seven launches)
+            loss_weighted = torch.ones(Is.shape[0], self.max_num_classes, device=self.dev)
+            # re-weight the loss, only support 1-way currently (trainer/trainers.py:962-963)
+            loss_weighted[torch.arange(loss_weighted.shape[0], device=self.dev), cls_idx.reshape(-1)] = self.lambda_
+            loss_k, loss_p, Yq_full_pre, Yq_pre = self.model.forward_step(Is, Ys, Iq, cls_idx, Yq, Yq_full,
+                                                                          loss_weighted)
+        else:
+            Yq_pre, Ys_pre, Yq_full_pre, Ys_full_pre = DENet_forward_wrapper(
+                self.model, self.model_cfg['arch'], Is, Ys, Iq, Yq, cls_idx, Ys_full, Yq_full)
         Yq_pre = Yq_pre.float()
         out_b, out_f = Yq_pre, Yq_full_pre
         if self.materialize:
@@ -296,11 +319,12 @@ class DENetTrainer(object):
             out_f = ops.upsample_bilinear(Yq_full_pre.detach(), Yq.shape[-2:])
         if self.testing:
             return out_b.detach(), out_f.detach()
-        loss_weighted = torch.ones(Yq_full_pre.shape[:2], device=self.dev)
-        # re-weight the loss, only support 1-way currently (trainer/trainers.py:962-963)
-        loss_weighted[torch.arange(loss_weighted.shape[0], device=self.dev), cls_idx.reshape(-1)] = self.lambda_
-        loss_k, loss_p = self.loss_func(Yq_pre, Yq, Ys_pre, Ys, Yq_full_pre, Yq_full, Ys_full_pre, Ys_full,
-                                        loss_weighted)
+        if not fused:
+            loss_weighted = torch.ones(Yq_full_pre.shape[:2], device=self.dev)
+            # re-weight the loss, only support 1-way currently (trainer/trainers.py:962-963)
+            loss_weighted[torch.arange(loss_weighted.shape[0], device=self.dev), cls_idx.reshape(-1)] = self.lambda_
+            loss_k, loss_p = self.loss_func(Yq_pre, Yq, Ys_pre, Ys, Yq_full_pre, Yq_full, Ys_full_pre, Ys_full,
+                                            loss_weighted)
         if train:
             self.bucket.zero()
             loss_k.backward()                       # only the knowledge loss (trainer/trainers.py:972-974)
@@ -318,7 +342,9 @@ class DENetTrainer(object):
             self.b_iou, self.f_iou = bIOU(), fIOU(num_classes=self.max_num_classes)
             for m in self.meters.values():
                 m.reset()
-            self.scheduler.step()
+            # pinned to the epoch like the reference's scheduler.step(epoch=epoch_idx) (trainer/trainers.py:209):
+            # a run resumed in epoch e (last_epoch = e in the checkpoint) must not tick to e + 1
+            tick(self.scheduler, epoch_idx)
             for batch_idx, batch in enumerate(self.train_loader, 1):
                 step_idx = (epoch_idx - 1) * len(self.train_loader) + batch_idx
                 Yq_pre, Yq_full_pre, loss, loss_k, loss_p = self.step(batch, train=True)
@@ -341,6 +367,7 @@ class DENetTrainer(object):
         meters = {k: AverageMeter() for k in ('loss', 'loss_k', 'loss_p')}
         b_iou, f_iou = bIOU(), fIOU(num_classes=self.max_num_classes)
         with torch.no_grad():
+            sharding.sync_buffers(self.model)
             for j, data in enumerate(self.val_loader):
                 Yq_pre, Yq_full_pre, loss, loss_k, loss_p = self.step(data, train=False)
                 local = sharding.shard_batch(tuple(data), self.rank, self.world)

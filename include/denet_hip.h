@@ -273,6 +273,33 @@ typedef struct denet_probe {
 
 int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C,
                                   int64_t h, int64_t w, int64_t H, int64_t W);
+
+/* Which kernel variant each launch of the step runs for a shape.  The launchers pick variants from the
+ * call's sizes alone (cache policy of the once-touched streams, classifier layout, loss-kernel path); this
+ * query runs the SAME decision functions and reports the outcome, so a test can assert that the shape it
+ * checks against the oracle exercises the variant a benchmark times.  No counterpart in the reference (one
+ * ATen op chain for every size).  `out` is a HOST pointer; nothing is enqueued. */
+#define DENET_CLS_TILE8   0   /* eight waves per 64-position tile (K <= 32, < 384 tiles in the batch) */
+#define DENET_CLS_UNITS   1   /* K > 32: (half tile, row tile) units dealt to eight waves             */
+#define DENET_CLS_WAVE4   2   /* a wave per tile, four tiles per block                                 */
+typedef struct denet_step_plan {
+    int32_t pool_launches;    /* 1: mask gathered inside the pooling kernel; 2: flat mask resize first       */
+    int32_t pool_long_rows;   /* rolling-loop pooling kernel (rows of more than 512 16-byte vectors)         */
+    int32_t pool_nt_loads;    /* Fs read with non-temporal loads (stream > 160 MB)                           */
+    int32_t classify_layout;  /* DENET_CLS_*                                                                 */
+    int32_t classify_groups;  /* DENET_CLS_UNITS: blocks per episode, else 0                                 */
+    int32_t loss_chain_cell;  /* 8 / 9: chain kernel with that many label columns per cell; 0: exact kernel  */
+    int32_t loss_chunk;       /* chain kernel: classes per table chunk                                       */
+    int32_t loss_xsplit;      /* column ranges per low-res row                                               */
+    int32_t bwd_persistent;   /* B1 runs the persistent-block kernel                                         */
+    int32_t bwd_groups;       /* dWn slabs per episode written by B1                                         */
+    int32_t bwd_dfq_nt;       /* dFq leaves B1 with non-temporal stores                                      */
+    int32_t dfs_nt;           /* dFs leaves B3 with non-temporal stores                                      */
+    int32_t dfs_flat_writer;  /* B3 writes the block's 16 rows as one span (fp32 + NT) instead of a row per wave */
+    int32_t reserved[3];
+} denet_step_plan_t;
+int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
+                         int64_t H, int64_t W, int feat_dtype, denet_step_plan_t* out);
 int denet_head_step_fwd(const void* Fq, const void* Fs, int feat_dtype, const int64_t* Ys,
                         const int64_t* labels, const int64_t* Yq, const int64_t* Yq_full,
                         const float* wgt, const float* weight, const float* W1, const float* b1,

@@ -366,10 +366,44 @@ def capture_trainer_glue():
     print("trainer_glue.npz", d["out:nway_mean"], d["out:nway_bf"])
 
 
+def capture_loss_variants():
+    """loss/losses.py:19-79 with the arguments no reference call site uses but the signatures take:
+    reduction 'sum' / 'none' and an ignore_index other than 255, for both loss functions, on low-res logits
+    (the up-sampling branch) -- inputs taken from api_cases.npz so the two fixtures share them."""
+    z = np.load(os.path.join(OUT, "api_cases.npz"))
+    full = torch.from_numpy(z["out:full"])
+    yf = torch.from_numpy(z["in:Yq_full"])
+    yq = torch.from_numpy(z["in:Yq"])[:, 1].contiguous()
+    binl = torch.from_numpy(z["out:bin_base_true"])
+    cw = torch.from_numpy(z["in:class_weight"])
+    d = {}
+    x = full.clone().requires_grad_(True)
+    l = ref_losses.cross_entropy2d(x, yf, weight=cw, reduction='sum')
+    l.backward()
+    d["out:ce_sum"], d["out:ce_sum_grad"] = l.detach().numpy(), x.grad.numpy()
+    d["out:ce_none"] = ref_losses.cross_entropy2d(full, yf, weight=cw, reduction='none').numpy()
+    # ignore_index = 2: class 2 is skipped; 255 is then an ordinary (out-of-range) label for torch, so the
+    # rows that carry it are relabelled 0 first
+    yf2 = torch.where(yf == 255, torch.zeros_like(yf), yf)
+    d["in:Yq_full_no255"] = yf2.numpy()
+    x = full.clone().requires_grad_(True)
+    l = ref_losses.cross_entropy2d(x, yf2, weight=cw, ignore_index=2)
+    l.backward()
+    d["out:ce_ign2"], d["out:ce_ign2_grad"] = l.detach().numpy(), x.grad.numpy()
+    d["out:focal_sum"] = ref_losses.binary_focal_loss(binl, yq, reduction='sum').numpy()
+    d["out:focal_none"] = ref_losses.binary_focal_loss(binl, yq, reduction='none').numpy()
+    d["out:focal_ign1_a03"] = ref_losses.binary_focal_loss(binl, yq, alpha=0.3, ignore_index=1).numpy()
+    np.savez_compressed(os.path.join(OUT, "loss_variants.npz"), **d)
+    print("loss_variants.npz", {k: float(np.asarray(v).reshape(-1)[0]) for k, v in d.items() if k.startswith("out:") and np.asarray(v).size < 4})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "glue":     # only the fixture added in round 2
         capture_trainer_glue()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss_variants":     # only the fixture added in round 3
+        capture_loss_variants()
         sys.exit(0)
     torch.set_num_threads(8)
     s1 = EpisodeShape("g1", N=2, way=1, shot=5, K=21, c=64, h=9, w=9, H=65, W=65, config_index=101, lam=2.5)
@@ -385,3 +419,4 @@ if __name__ == "__main__":
     capture_fullsize_checksums()
     capture_api_cases()
     capture_trainer_glue()
+    capture_loss_variants()

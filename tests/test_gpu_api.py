@@ -42,7 +42,9 @@ def test_weight_estimator_module_eval(name, dev):
     if "out:weights" in z.files:
         assert rel_err(Wn.detach().cpu(), z["out:weights"]) < TIGHT
     logits2 = we.infer(Fq, Wn)
-    assert torch.equal(logits2.detach(), logits.detach())
+    # (the no-grad forward above ran the fused step's forward launches -- sliced gate / projection chain --,
+    # extend + infer the stand-alone kernels: same arithmetic, different summation order inside the mat-vecs)
+    assert rel_err(logits2.detach(), logits.detach()) < 2e-6
     from denet_amd.losses import loss_denet_batch
     full, binl = we.forward_with_binary(Fq, Fs, Ys, lab)
     assert rel_err(binl.cpu(), z["out:logits_binary"]) < TIGHT
@@ -222,7 +224,31 @@ def test_trainer_train_val_test_roundtrip(dev, tmp_path):
     out = tl.step(tl.test_loader.batch(0), train=False)
     assert out[0].shape == (8, 2, 9, 9) and out[1].shape == (4, 21, 9, 9)
     mb2, mf2 = tl.test()
-    assert abs(mb2 - mb) < 5e-3 and abs(mf2 - mf) < 5e-3      # a few sub-margin arg-max flips at most
+    # the two paths may only disagree on pixels whose top-2 margin is below 1e-4: count those
+    # pixels on the materialised outputs and bound the difference of the two paths' COUNTS by them
+    from denet_amd.metrics import BinaryIOU, FullIOU
+    fa, fb, ba, bb, sub_f, sub_b = FullIOU(21), FullIOU(21), BinaryIOU(), BinaryIOU(), 0, 0
+    for j in range(len(te.test_loader)):
+        batch = te.test_loader.batch(j)
+        Yq, cls_idx, Yq_full = batch[3], batch[4], batch[6]
+        up_b, up_f = te.step(batch, train=False)
+        lo_b, lo_f = tl.step(batch, train=False)
+        fa.update(Yq_full, up_f)
+        fb.update(Yq_full, lo_f)
+        top = up_f.topk(2, dim=1)[0]
+        sub_f += int((((top[:, 0] - top[:, 1]) <= 1e-4).cpu() & (Yq_full != 255)).sum())
+        n, way = Yq.shape[:2]
+        ub, lb = up_b.reshape(n, way, *up_b.shape[-3:]), lo_b.reshape(n, way, *lo_b.shape[-3:])
+        for i in range(way):
+            ba.update(Yq[:, i], ub[:, i].contiguous(), cls_idx[:, i].numpy())
+            bb.update(Yq[:, i], lb[:, i].contiguous(), cls_idx[:, i].numpy())
+        sub_b += int(((up_b[:, 0] - up_b[:, 1]).abs() <= 1e-4).sum())
+    assert int(np.abs(fa.counts() - fb.counts()).sum()) <= 2 * sub_f          # a flip moves one count to another bin
+    assert list(ba.inter) == list(bb.inter)
+    assert sum(abs(ba.inter[c] - bb.inter[c]) + abs(ba.union[c] - bb.union[c]) for c in ba.inter) <= 2 * sub_b
+    if sub_f == 0 and sub_b == 0:
+        assert mb2 == mb and mf2 == mf
+    print(f"materialised vs fused metric paths: {sub_f} / {sub_b} sub-margin pixels (full / binary)")
     with pytest.raises(ValueError):
         DENetTrainer(cfg, tcfg)
 

@@ -1,0 +1,226 @@
+"""GPU: the reference's own call sequence for a training step -- model(...) -> two F.interpolate -> loss_func ->
+loss_k.backward() (trainer/trainers.py:951-975) -- lands on the fused seven-launch head step when driven through
+the drop-in API (DENet.forward_step / WeightEstimator.head_step / DENetTrainer.step), plus the loss-function
+arguments the reference's signatures take but none of its call sites use (loss/losses.py:19,47)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, assert_close, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+ORDER = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+         "map.linear.weight", "map.linear.bias"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _feature_stub_model(K, c, dev):
+    """DENet whose producer is the identity: the 'images' ARE the feature maps, so forward_step's gradients
+    w.r.t. its image arguments are dFs / dFq and can be compared with the oracle's."""
+    from denet_amd.head import DENet
+
+    class FeatureStub(DENet):
+        def features(self, images):
+            return images
+
+    m = FeatureStub(backbone=torch.nn.Identity(), maximum_num_classes=K, depth=c, visualize=False)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("name", ["eval_1way_5shot", "eval_2way_3shot"])
+def test_forward_step_is_one_fused_node_and_matches_the_reference(name, dev):
+    """forward_step == the fixture captured from the reference's estimator + up-sampling + loss wrapper +
+    autograd, and bit-equal to ops.HeadStepFunction on the same tensors (it IS that node)."""
+    from denet_amd import ops
+    z, d, ep, params, gm, wm = load_case(name)
+    N, way = d["N"], d["way"]
+    m = _feature_stub_model(d["K"], d["c"], dev).eval()
+    m.estimator.load_state_dict(params)
+    Fs = ep["Fs"].float().to(dev).requires_grad_(True)
+    Fq = ep["Fq"].float().to(dev).requires_grad_(True)
+    lab = ep["label"].reshape(N, way).to(dev)
+    lk, lp, full, binl = m.forward_step(Fs, ep["Ys"].to(dev), Fq, lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev),
+                                        ep["wgt"].to(dev))
+    assert type(lk.grad_fn).__name__ == "HeadStepFunctionBackward"
+    lk.backward()
+    assert rel_err(full.cpu(), z["out:logits_full"]) < 2e-5
+    assert rel_err(binl.cpu(), z["out:logits_binary"]) < 2e-5
+    assert rel_err(lk.detach().cpu(), z["out:loss_k"]) < 1e-4 and rel_err(lp.cpu(), z["out:loss_p"]) < 1e-4
+    assert_close(Fq.grad.cpu(), z["out:dFq"], 1e-3, "dFq")
+    assert_close(Fs.grad.cpu(), z["out:dFs"], 1e-3, "dFs")
+    got = {k: p.grad.clone() for k, p in m.estimator.named_parameters()}
+    for k, g in got.items():
+        assert rel_err(g.cpu(), z["grad:" + k]) < 1e-3, k
+    # the same tensors through the autograd node directly: bit for bit
+    P = [dict(m.estimator.named_parameters())[k].detach().clone().requires_grad_(True) for k in ORDER]
+    Fs2, Fq2 = Fs.detach().clone().requires_grad_(True), Fq.detach().clone().requires_grad_(True)
+    lk2, lp2, full2, bin2 = ops.HeadStepFunction.apply(
+        Fq2, Fs2, *P, ep["Ys"].to(dev), lab, ep["Yq"].reshape(N * way, d["H"], d["W"]).to(dev),
+        ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+    lk2.backward()
+    assert torch.equal(lk2, lk) and torch.equal(lp2, lp) and torch.equal(full2, full) and torch.equal(bin2, binl)
+    assert torch.equal(Fs2.grad, Fs.grad) and torch.equal(Fq2.grad, Fq.grad)
+    for k, p in zip(ORDER, P):
+        assert torch.equal(p.grad, got[k]), k
+    # validation steps: no graph under no_grad, same numbers, and the workspace goes straight back to the pool
+    with torch.no_grad():
+        lk3, lp3, full3, _ = m.forward_step(Fs, ep["Ys"].to(dev), Fq, lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev),
+                                            ep["wgt"].to(dev))
+    assert lk3.grad_fn is None and torch.equal(full3, full) and rel_err(lk3.cpu(), lk.detach().cpu()) < 1e-6
+    assert sum(len(v) for v in ops.workspace_pool._free.values()) >= 1
+
+
+def test_train_mode_forward_step_draws_in_kernel_dropout(dev):
+    """Train mode: ONE seed per step, masks generated in the kernels; equals the same step fed the masks
+    denet_dropout_mask writes for that seed through the injected-mask pointers (the path the reference fixture
+    train_1way_5shot pins, tests/test_gpu_dropout.py)."""
+    from denet_amd import ops
+    z, d, ep, params, gm, wm = load_case("train_1way_5shot")
+    N, way, shot, K, c = d["N"], d["way"], d["shot"], d["K"], d["c"]
+    m = _feature_stub_model(K, c, dev).train()
+    m.estimator.load_state_dict(params)
+    Fs, Fq = ep["Fs"].float().to(dev), ep["Fq"].float().to(dev)
+    lab = ep["label"].reshape(N, way).to(dev)
+    args = (ep["Ys"].to(dev), Fq, lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev), ep["wgt"].to(dev))
+    torch.manual_seed(5)
+    lk, lp, full, binl = m.forward_step(Fs, *args)
+    lk.backward()
+    seed = m.estimator.last_dropout_seed
+    g1 = {k: p.grad.clone() for k, p in m.estimator.named_parameters()}
+    torch.manual_seed(6)
+    lkb, _, fullb, _ = m.forward_step(Fs, *args)
+    assert m.estimator.last_dropout_seed != seed and not torch.equal(fullb, full)      # a new seed every step
+    gmask = ops.dropout_mask(seed, ops.DROPOUT_GATE, 0.5, (N * way * shot, c), dev)
+    wmask = ops.dropout_mask(seed, ops.DROPOUT_WEIGHT, 0.5, (N, K, c), dev)
+    m.zero_grad()
+    lk2, lp2, full2, bin2 = m.estimator.head_step(Fq, Fs, args[0], lab, args[3], args[4], args[5],
+                                                  gate_mask=gmask, weight_mask=wmask)
+    lk2.backward()
+    assert torch.equal(full2, full) and torch.equal(lk2, lk) and torch.equal(bin2, binl)
+    for k, p in m.estimator.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+
+
+def test_trainer_step_runs_the_fused_step(dev, tmp_path):
+    """DENetTrainer.step (train and val) = conv stack + ONE HeadStepFunction: the estimator gradients the
+    trainer's bucket holds after a train step equal, bit for bit, those of the hand-driven sequence
+    features -> HeadStepFunction(drop=seed) -> backward under the same RNG state; the loss equals the oracle's on
+    the same features; resuming restores the scheduler at the checkpoint's epoch."""
+    from denet_amd import ops
+    from denet_amd.trainer import DENetTrainer
+    from oracle import denet_oracle as O
+    cfg = {
+        "model": {"arch": "DENet", "backbone": "synthetic", "maximum_num_classes": 21},
+        "data": {"train_dataset": "synthetic", "val_dataset": "synthetic", "img_size": 65, "shot": 2,
+                 "batch_size": 4, "batches_per_epoch": 2, "val_batches": 1},
+        "train": {"trainer": "DENetTrainer", "device": 0, "num_steps": 6, "log_steps": 100, "val_steps": 2,
+                  "lambda": 2.0, "logdir": str(tmp_path),
+                  "optimizer": {"name": "sgd", "lr": 0.05, "momentum": 0.9},
+                  "scheduler": {"name": "StepLR", "step_size": 1, "gamma": 0.5},
+                  "loss": {"name": "loss_denet"}},
+    }
+    torch.manual_seed(0)
+    tr = DENetTrainer(cfg)
+    assert tr.loss_func.fused_head_step
+    batch = tr.train_loader.batch(0)
+    Is, Ys, Iq, Yq, cls, Ys_full, Yq_full = [t.to(dev) for t in batch]
+    N, way, shot = Is.shape[:3]
+    wgt = torch.ones(N, 21, device=dev)
+    wgt[torch.arange(N, device=dev), cls.reshape(-1)] = 2.0
+    model, est = tr.model, tr.model.estimator
+    names = ["estimator." + k for k in ORDER]
+    params = dict(model.named_parameters())
+
+    # --- eval: loss against the oracle on the same features
+    model.eval()
+    with torch.no_grad():
+        Fs = model.features(Is.reshape(-1, *Is.shape[3:])).reshape(N, way, shot, 256, 9, 9)
+        Fq = model.features(Iq)
+        out = tr.step(batch, train=False)
+    state = {k: v.detach().cpu() for k, v in est.state_dict().items()}
+    ref = O.head_step(Fq.cpu(), Fs.cpu(), batch[1], batch[4], batch[3], batch[6], wgt.cpu(), state, backward=False)
+    assert abs(out[3] - float(ref["loss_k"])) < 1e-4 * abs(float(ref["loss_k"]))
+    assert abs(out[4] - float(ref["loss_p"])) < 1e-4 * abs(float(ref["loss_p"]))
+    assert out[0].shape == (4, 2, 65, 65) and out[1].shape == (4, 21, 65, 65)
+
+    # --- train: the hand-driven sequence first (parameters untouched), then the trainer's own step
+    model.train()
+    torch.manual_seed(123)
+    Fs = model.features(Is.reshape(-1, *Is.shape[3:])).reshape(N, way, shot, 256, 9, 9)
+    Fq = model.features(Iq)
+    drop = est.dropout_config()
+    lk, lp, _, _ = ops.HeadStepFunction.apply(Fq, Fs, *[params[n] for n in names], Ys, cls.reshape(N, way),
+                                              Yq.reshape(N * way, 65, 65), Yq_full, wgt, None, None, drop)
+    tr.bucket.zero()
+    lk.backward()
+    hand = {n: params[n].grad.clone() for n in names}
+    hand_loss = float(lk)
+    torch.manual_seed(123)
+    out = tr.step(batch, train=True)
+    assert est.last_dropout_seed == drop[0]
+    assert out[3] == hand_loss
+    for n in names:
+        assert torch.equal(params[n].grad, hand[n]), n
+    assert float(params["embedding.0.weight"].grad.abs().sum()) > 0         # dFq / dFs reached the conv stack
+
+    # --- resume: epoch-pinned scheduler (trainer/trainers.py:209): lr of epoch e after a reload = lr of epoch e
+    tr.train()
+    lrs = {}
+    ck = torch.load(str(tmp_path / "latest_model.bin"), weights_only=True)
+    e = ck["epoch"]
+    cfg2 = {**cfg, "train": {**cfg["train"], "resume": str(tmp_path / "latest_model.bin")}}
+    tr2 = DENetTrainer(cfg2)
+    assert tr2.start_epoch == e and tr2.scheduler.last_epoch == ck["scheduler"]["last_epoch"]
+    from denet_amd.schedulers import tick
+    tick(tr2.scheduler, e)
+    assert abs(tr2.optimizer.param_groups[0]["lr"] - 0.05 * 0.5 ** e) < 1e-12
+
+
+def test_loss_arguments_beyond_the_reference_defaults(dev):
+    """reduction='sum' / 'none' and ignore_index != 255 for both losses, against the reference's own functions
+    (tests/golden/loss_variants.npz, written by oracle/gen_golden.py loss_variants)."""
+    from denet_amd import losses
+    za, z = np.load(GOLDEN + "/api_cases.npz"), np.load(GOLDEN + "/loss_variants.npz")
+    full = torch.from_numpy(za["out:full"]).to(dev)
+    yf = torch.from_numpy(za["in:Yq_full"]).to(dev)
+    cw = torch.from_numpy(za["in:class_weight"]).to(dev)
+    x = full.clone().requires_grad_(True)
+    l = losses.cross_entropy2d(x, yf, weight=cw, reduction='sum')
+    l.backward()
+    assert rel_err(l.detach().cpu(), z["out:ce_sum"]) < 1e-5
+    assert_close(x.grad.cpu(), z["out:ce_sum_grad"], 1e-3, "d ce_sum")
+    none = losses.cross_entropy2d(full, yf, weight=cw, reduction='none')
+    assert_close(none.cpu(), z["out:ce_none"], 2e-5, "ce_none", afloor=1e-5)
+    yf2 = torch.from_numpy(z["in:Yq_full_no255"]).to(dev)
+    x = full.clone().requires_grad_(True)
+    l = losses.cross_entropy2d(x, yf2, weight=cw, ignore_index=2)
+    l.backward()
+    assert rel_err(l.detach().cpu(), z["out:ce_ign2"]) < 1e-5
+    assert_close(x.grad.cpu(), z["out:ce_ign2_grad"], 1e-3, "d ce_ign2")
+    yq = torch.from_numpy(za["in:Yq"])[:, 1].contiguous().to(dev)
+    binl = torch.from_numpy(za["out:bin_base_true"]).to(dev)
+    assert rel_err(losses.binary_focal_loss(binl, yq, reduction='sum').cpu(), z["out:focal_sum"]) < 1e-5
+    assert_close(losses.binary_focal_loss(binl, yq, reduction='none').cpu(), z["out:focal_none"], 2e-5, "focal_none",
+                 afloor=1e-5)
+    assert rel_err(losses.binary_focal_loss(binl, yq, alpha=0.3, ignore_index=1).cpu(), z["out:focal_ign1_a03"]) < 1e-5
+    with pytest.raises(ValueError):
+        losses.cross_entropy2d(full, yf, reduction='median')
+
+
+def test_standalone_pooling_long_rows_fp32(dev):
+    """Stand-alone denet_masked_sum_fwd on fp32 rows of more than 2048 positions: the rolling loop over a
+    row-major mask image (the fused step parks the gate weights behind that image; stand-alone there is
+    padding instead)."""
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, C, h, w = 3, 64, 50, 53                       # P = 2650 > 2048, odd
+    Fs = torch.randn(B, C, h, w, generator=g)
+    mask = (torch.rand(B, h * w, generator=g) > 0.4).float()
+    S = ops.masked_sum(Fs.to(dev), mask.to(dev))
+    ref = (Fs.reshape(B, C, -1).double() * mask.unsqueeze(1).double()).sum(-1)
+    assert rel_err(S.cpu(), ref) < 2e-6

@@ -133,6 +133,77 @@ def test_c5_bf16_large_resolution_against_oracle(dev):
     _confmat_check(out["logits_full"], ep, s.K, dev)
 
 
+def _plan(s):
+    from denet_amd import _lib
+    return _lib.head_step_plan(s.N, s.way, s.shot, s.K, s.c, s.h, s.w, s.H, s.W,
+                               _lib.BF16 if s.feat_dtype == "bf16" else _lib.F32)
+
+
+def _check_step_against_oracle(s, dev, gtol):
+    from oracle import denet_oracle as O
+    ep, state, out = _run_step(s, dev)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    assert rel_err(out["logits_full"].cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(out["logits_binary"].cpu(), ref["logits_binary"]) < 2e-5
+    assert rel_err(out["loss_k"].cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(out["loss_p"].cpu(), ref["loss_p"]) < 1e-4
+    assert rel_err(out["Fq"].grad.float().cpu(), ref["dFq"]) < gtol
+    assert rel_err(out["Fs"].grad.float().cpu(), ref["dFs"]) < gtol
+    for k, t in zip(ORDER, out["P"]):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 1e-3, k
+    return ep, out
+
+
+def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
+    """C3 forward AND backward at the 20 episodes profiles/*_bench_c3.json times, against the oracle (about a
+    second on the host).  The launchers pick kernel variants from the sizes alone; the plan query reports what
+    this shape runs, so the test fails if a threshold moves the benchmark onto a path it does not check:
+    flat mask resize + non-temporal Fs loads (344 MB), classifier layout (a) with 12 blocks per episode,
+    chain loss kernel on 8-column cells, persistent backward with 6 tile groups, non-temporal dFq stores,
+    the flat non-temporal fp32 dFs writer."""
+    from denet_amd import _lib
+    from denet_amd.synthetic import CONFIGS
+    s = CONFIGS["C3"]
+    assert s.N == 20
+    pl = _plan(s)
+    assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 0
+    assert pl["classify_layout"] == _lib.CLS_UNITS and pl["classify_groups"] == 12
+    assert pl["loss_chain_cell"] == 8 and 1 < (s.K + pl["loss_chunk"] - 1) // pl["loss_chunk"] <= 5
+    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 6 and pl["bwd_dfq_nt"] == 1
+    assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 1
+    _check_step_against_oracle(s, dev, 2e-5)
+
+
+def test_c5_at_the_benchmarked_batch(dev):
+    """C5 at the 8 episodes profiles/*_bench_c5.json times (the N = 2 case above stays below every size
+    threshold): long-row bf16 pooling with non-temporal loads (269 MB), flat mask resize, classifier layout (b),
+    chain loss kernel on 9-column cells, persistent backward with 15 tile groups, the bf16 row writer under
+    non-temporal stores."""
+    from denet_amd import _lib
+    from denet_amd.synthetic import CONFIGS
+    s = CONFIGS["C5"]
+    assert s.N == 8 and s.feat_dtype == "bf16"
+    pl = _plan(s)
+    assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 1
+    assert pl["classify_layout"] == _lib.CLS_WAVE4
+    assert pl["loss_chain_cell"] == 9
+    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 15 and pl["bwd_dfq_nt"] == 1
+    assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 0
+    ep, out = _check_step_against_oracle(s, dev, 8e-3)
+    assert out["Fs"].grad.dtype == torch.bfloat16
+
+
+def test_c2_plan_at_the_headline_batch():
+    """The headline configuration's variants (everything cached, in-kernel mask gather, eight-wave classifier),
+    which test_c2_fullsize_against_reference_checksums checks against the reference's own run."""
+    from denet_amd import _lib
+    from denet_amd.synthetic import CONFIGS
+    pl = _plan(CONFIGS["C2"])
+    assert pl["pool_launches"] == 1 and pl["pool_nt_loads"] == 0 and pl["classify_layout"] == _lib.CLS_TILE8
+    assert pl["loss_chain_cell"] == 8 and pl["loss_chunk"] == 21
+    assert pl["bwd_groups"] == 14 and pl["dfs_nt"] == 0 and pl["bwd_dfq_nt"] == 1
+
+
 @pytest.mark.parametrize("feat_dtype", ["f32", "bf16"])
 def test_c2_sixteen_episodes_batch_paths_against_oracle(dev, feat_dtype):
     """C2's shape at 16 episodes takes the batch paths of the K <= 32 kernels: 432 position tiles -> the

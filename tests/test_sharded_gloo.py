@@ -83,7 +83,20 @@ def _worker(rank, port, tmp):
     lin(x).pow(2).mean().backward()
     local = bucket.flat.clone()
     bucket.all_reduce_mean()
+    # BatchNorm running buffers: every rank saw its own shard's statistics; sync_buffers makes them one model
+    bn = torch.nn.BatchNorm2d(3)
+    bn.train()
+    bn(torch.randn(4, 3, 5, 5, generator=torch.Generator().manual_seed(7 + rank)) * (1 + rank) + rank)
+    bn_local = {k: v.clone() for k, v in bn.state_dict().items()}
+    sharding.sync_buffers(bn)
+    # train-mode dropout seed: torch's generator starts from the same state on every rank, the seeds must not
+    from denet_amd.head import WeightEstimator
+    torch.manual_seed(0)
+    we = WeightEstimator(5, 64).train()
+    seeds = [we.dropout_config()[0] for _ in range(3)]
     torch.save({"mat": fi.counts(), "miou": float(fi.mean_iou()), "keys": list(bi.inter.keys()),
+                "bn_local": bn_local, "bn_synced": {k: v.clone() for k, v in bn.state_dict().items()},
+                "seeds": seeds,
                 "inter": list(bi.inter.values()), "union": list(bi.union.values()), "biou": bi.mean_iou(),
                 "bf": bi.mean_bf_iou(), "grad_local": local, "grad_avg": bucket.flat.clone()},
                os.path.join(tmp, f"r{rank}.pt"))
@@ -106,3 +119,13 @@ def test_world2_metrics_and_gradients_match_single_process():
     assert torch.allclose(res[0]["grad_avg"], avg, rtol=0, atol=1e-6)
     assert torch.equal(res[0]["grad_avg"], res[1]["grad_avg"])
     assert not torch.equal(res[0]["grad_local"], res[1]["grad_local"])
+    # buffers: mean of the ranks' running statistics, identical everywhere; the step counter from rank 0
+    for k in ("running_mean", "running_var"):
+        mean = (res[0]["bn_local"][k] + res[1]["bn_local"][k]) / 2
+        assert not torch.equal(res[0]["bn_local"][k], res[1]["bn_local"][k])
+        assert torch.allclose(res[0]["bn_synced"][k], mean, rtol=0, atol=1e-6)
+        assert torch.equal(res[0]["bn_synced"][k], res[1]["bn_synced"][k])
+    assert int(res[1]["bn_synced"]["num_batches_tracked"]) == int(res[0]["bn_local"]["num_batches_tracked"])
+    # dropout seeds: same torch generator state on both ranks, distinct seeds per rank and per step
+    assert len(set(res[0]["seeds"]) | set(res[1]["seeds"])) == 6
+    assert [s % WORLD for s in res[0]["seeds"]] == [0, 0, 0] and [s % WORLD for s in res[1]["seeds"]] == [1, 1, 1]
