@@ -597,7 +597,7 @@ def run(args):
         dist.destroy_process_group()
 
 
-def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=60):
+def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=200):
     """The same batch through the reference-shaped Python API, fwd + both losses + loss_k.backward(), us per
     step (host-synchronised loop of `steps` steps after 10 warm-up steps):
       * `head_step`: WeightEstimator.head_step -- what DENet.forward_step / DENetTrainer.step run: ONE
@@ -622,19 +622,22 @@ def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=60):
         lk.backward()
 
     res = {}
+    leaves = [Fq, Fs] + list(we.parameters())
     for name, fn in (("head_step", fused), ("standalone", standalone)):
         for _ in range(10):
-            we.zero_grad(set_to_none=True)
-            Fq.grad = Fs.grad = None
+            for t in leaves:
+                t.grad = None
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            we.zero_grad(set_to_none=True)
-            Fq.grad = Fs.grad = None
+            for t in leaves:
+                t.grad = None
             fn()
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         res[name + "_us_per_step"] = round((time.perf_counter() - t0) / steps * 1e6, 1)
+        res[name + "_host_enqueue_us"] = round((t1 - t0) / steps * 1e6, 1)
     res["steps"] = steps
     res["episodes_per_s_head_step"] = round(shape.N / (res["head_step_us_per_step"] * 1e-6), 1)
     res["note"] = ("eval mode, same C-ABI kernels as the headline; head_step = WeightEstimator.head_step "

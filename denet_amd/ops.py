@@ -451,7 +451,7 @@ class _WorkspacePool:
         self._free = {}
 
     def take(self, nbytes, device):
-        key = (device.index, torch.cuda.current_stream(device).cuda_stream, int(nbytes))
+        key = (device.index, _lib.current_stream_handle(device.index), int(nbytes))
         free = self._free.get(key)
         if free:
             return key, free.pop()
