@@ -623,6 +623,8 @@ def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=200):
 
     res = {}
     leaves = [Fq, Fs] + list(we.parameters())
+    gc.collect()
+    gc.disable()                # (as in the main timed region: no collector pause charged to a step)
     for name, fn in (("head_step", fused), ("standalone", standalone)):
         for _ in range(10):
             for t in leaves:
@@ -638,6 +640,7 @@ def dropin_leg(torch, shape, ep, labels, state_cpu, dev, fdt, steps=200):
         torch.cuda.synchronize()
         res[name + "_us_per_step"] = round((time.perf_counter() - t0) / steps * 1e6, 1)
         res[name + "_host_enqueue_us"] = round((t1 - t0) / steps * 1e6, 1)
+    gc.enable()
     res["steps"] = steps
     res["episodes_per_s_head_step"] = round(shape.N / (res["head_step_us_per_step"] * 1e-6), 1)
     res["note"] = ("eval mode, same C-ABI kernels as the headline; head_step = WeightEstimator.head_step "

@@ -440,6 +440,20 @@ class UpsampleFocalFunction(torch.autograd.Function):
 # --------------------------------------------------------------------------
 # autograd: the fused head step (T1)
 # --------------------------------------------------------------------------
+_ws_bytes_cache = {}
+
+
+def _step_workspace_bytes(*dims):
+    """denet_head_step_workspace for a shape, remembered (one ctypes call less per step)."""
+    n = _ws_bytes_cache.get(dims)
+    if n is None:
+        n = query("denet_head_step_workspace", *dims)
+        if n < 0:
+            raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(n)}")
+        _ws_bytes_cache[dims] = n
+    return n
+
+
 class _WorkspacePool:
     """Step workspaces by (device, stream, bytes): the fused step's scratch slab (~150 MB at C2) is handed from
     one step to the next instead of going through the allocator on every call.  A forward takes a slab, the
@@ -494,13 +508,13 @@ class HeadStepFunction(torch.autograd.Function):
         Yq = _as_i64(Yq).contiguous() if Yq is not None else None
         Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
         need = any(ctx.needs_input_grad[:9])          # (false under no_grad as well: validation steps)
-        nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
-        if nbytes < 0:
-            raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(nbytes)}")
+        nbytes = _step_workspace_bytes(N, way, shot, K, C, h, w, H, W)
         ws_key, ws = workspace_pool.take(nbytes, dev)
         logits = _f32(N, K, h, w, device=dev)
         binl = _f32(N * way, 2, h, w, device=dev)
-        losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        # (both entries are written by the step when both label maps are given: no memset launch then)
+        losses = _f32(2, device=dev) if (Yq is not None and Yq_full is not None) else \
+            torch.zeros(2, dtype=torch.float32, device=dev)
         call("denet_head_step_train_fwd", Fq, Fs, feat_code(Fq, Fs), Ys, labels, Yq, Yq_full, wgt, *params,
              gate_mask, weight_mask, ctx.drop, N, way, shot, K, C, h, w, H, W, 1 if need else 0, logits, binl, losses,
              ws, nbytes, None)
@@ -562,9 +576,7 @@ def head_forward(Fq, Fs, params, Ys, labels, gate_mask=None, weight_mask=None, d
     labels = _as_i64(labels).contiguous()
     Ys = _as_i64(Ys).contiguous()
     H, W = Ys.shape[-2:]
-    nbytes = query("denet_head_step_workspace", N, way, shot, K, C, h, w, H, W)
-    if nbytes < 0:
-        raise _lib.DenetHipError(f"denet_head_step_workspace: {_lib.strerror(nbytes)}")
+    nbytes = _step_workspace_bytes(N, way, shot, K, C, h, w, H, W)
     ws_key, ws = workspace_pool.take(nbytes, dev)
     logits = _f32(N, K, h, w, device=dev)
     binl = _f32(N * way, 2, h, w, device=dev)
