@@ -26,6 +26,7 @@ _SIGS = {
     "denet_mask_resize": "L" "lllll" "FF",
     "denet_masked_sum_fwd": "piF" "lll" "F",
     "denet_masked_sum_bwd": "FF" "lll" "pi",
+    "denet_masked_sum_bwd_chunked": "FF" "lll" "pi",
     "denet_masked_pool_fwd": "piL" "llllll" "FFF",
     "denet_proto_extend_fwd": "FFFFFFFFF" "L" "FF" "llllll" "FFFFF",
     "denet_proto_extend_bwd": "Fl" "FFFFF" "FFF" "LFF" "llllll" "FFFFFFFF" "pl",
@@ -84,7 +85,7 @@ class StepPlan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "pool_launches", "pool_long_rows", "pool_nt_loads", "classify_layout", "classify_groups",
         "loss_chain_cell", "loss_chunk", "loss_xsplit", "bwd_persistent", "bwd_groups", "bwd_dfq_nt",
-        "dfs_nt", "dfs_flat_writer")] + [("reserved", ctypes.c_int32 * 3)]
+        "dfs_nt", "dfs_flat_writer", "dfs_chunked")] + [("reserved", ctypes.c_int32 * 2)]
 
 
 CLS_TILE8, CLS_UNITS, CLS_WAVE4 = 0, 1, 2

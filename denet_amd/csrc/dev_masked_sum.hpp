@@ -328,6 +328,8 @@ struct CoefArgs {
     const float *dh_part, *hidden, *W1, *dpool, *gate, *cnt;
     int shot, nsl;
     float Pf, eps;
+    float* coef_out;      // not null: the block only writes its 16 coefficients to coef_out [B][C] (the stream is
+                          // written by dfs_chunk_kernel afterwards)
 };
 
 // NT: non-temporal stores.  A cached dFs stream leaves the last-level cache full of dirty lines whose write-back
@@ -375,6 +377,26 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
         cg = ca.gate[(int64_t)b * C + c0 + t16];
         cd = ca.dpool[(int64_t)(b / ca.shot) * C + c0 + t16];
         cc = ca.cnt[b] + ca.eps;
+    }
+    if constexpr (SLICED) {
+        if (ca.coef_out != nullptr) {                 // block-uniform: coefficients only
+            float dh = 0.f;
+#pragma unroll
+            for (int q = 0; q < NSLT; ++q) dh += dhv[q];
+            const float dpre = ((int)threadIdx.x < C && hid > 0.f) ? dh : 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float v = wave_sum(w1v[t >> 2][t & 3] * dpre);
+                if (lane == t) red[wave * 16 + t] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 16 && c0 + (int)threadIdx.x < C) {
+                const int t = threadIdx.x;
+                const float datt = ((red[t] + red[16 + t]) + red[32 + t]) + red[48 + t];
+                ca.coef_out[(int64_t)b * C + c0 + t] = cd * (cg / cc) + datt / ca.Pf;
+            }
+            return;
+        }
     }
     float mv[8];
 #pragma unroll
@@ -494,6 +516,70 @@ __device__ __forceinline__ void masked_sum_bwd_body(const float* __restrict__ ma
         }
         const int t0 = head + nvec * V;
         if (t0 + (int)threadIdx.x < total) FeatIO<T>::store(out + t0 + threadIdx.x, value(t0 + threadIdx.x));
+    }
+}
+
+// The dFs stream of large batches: dFs[r][p] = coef[r] * mask[r / C][p] over the FLAT tensor, one block per
+// contiguous chunk of 256 * U 16-byte vectors, blocks in address order.  The chip then writes ONE compact moving
+// window (resident blocks x chunk) like a fill kernel instead of one 107 KB span per resident 16-row block:
+// scripts/diag/write_ceiling.hip measures 6.6-6.7 TB/s for this pattern against 5.0 for per-block spans (and 6.3-6.6
+// for hipMemset) on 344 MB.  No LDS: the mask (B * P floats, L2 / last-level-cache resident) is read with one
+// unaligned 16-byte load per 16 bytes stored (rows are only element-aligned: P is odd), the row's coefficient with
+// a 4-byte load; a vector that straddles two rows (one in ~P / V) is formed element by element.  Needs the
+// coefficients as a tensor (CoefArgs::coef_out: the tail kernel's dFs blocks in coefficient-only mode).
+typedef float f32x4_mu __attribute__((ext_vector_type(4), aligned(4)));
+// grid (chunks per image, B): block (x, b) writes elements [x * CHUNK, (x + 1) * CHUNK) of image b's C * P span
+// (C * P < 2^22 elements, so every index fits the float-reciprocal divmod; an image's span starts 16-byte aligned:
+// C is a multiple of 64).  blockIdx.x runs fastest: dispatch order = address order.
+template <typename T, int U>
+__global__ __launch_bounds__(256) void dfs_chunk_kernel(const float* __restrict__ mask, const float* __restrict__ coef,
+                                                       T* __restrict__ dFs, int C, int P) {
+    constexpr int V = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    constexpr int CHUNK = 256 * U * V;               // elements per block
+    const int b = blockIdx.y;
+    const int span = C * P;
+    const float invP = 1.f / (float)P;
+    const float* mr = mask + (int64_t)b * P;
+    const float* cf = coef + (int64_t)b * C;
+    T* out = dFs + (int64_t)b * span;
+    f32x4_mu m[U][V / 4];
+    float k0[U];
+    int pp[U], rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // clamped, unconditional loads (vectors past the span's end are not stored)
+        const int e0 = min((int)blockIdx.x * CHUNK + (u * 256 + (int)threadIdx.x) * V, span - 1);
+        int p;
+        const int r = wc_divmod_p(e0, P, invP, p);
+        pp[u] = p;
+        rr[u] = r;
+        k0[u] = cf[r];
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) m[u][q] = *reinterpret_cast<const f32x4_mu*>(mr + max(min(p + 4 * q, P - 4), 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e0 = (int)blockIdx.x * CHUNK + (u * 256 + (int)threadIdx.x) * V;
+        if (e0 >= span) continue;
+        const int p = pp[u];
+        if (p + V <= P) {                            // (then e0 + V <= span as well)
+            vec_t v;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float x = k0[u] * m[u][e >> 2][e & 3];
+                if constexpr (V == 4) v[e] = x;
+                else v[e] = f32_to_bf16(x);
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(out + e0));
+        } else {
+            // the vector crosses a row boundary (one in ~P / V) or the span's end: element by element
+            for (int e = 0; e < V && e0 + e < span; ++e) {
+                const bool wrap = p + e >= P;
+                const float x = cf[rr[u] + (wrap ? 1 : 0)] * mr[wrap ? p + e - P : p + e];
+                FeatIO<T>::store(out + e0 + e, x);
+            }
+        }
     }
 }
 

@@ -12,7 +12,7 @@
 
 struct HeadWs {
     float *mask, *cnt, *S, *hidden, *gate, *pool, *Wn, *part_k, *part_p, *scale, *dlog_a, *dlog_b, *dWn_part,
-        *pre1_part, *proto_part, *dh_part, *dpool, *u2, *u3;
+        *pre1_part, *proto_part, *dh_part, *dpool, *u2, *u3, *coef;
     int64_t total;   // bytes
 };
 
@@ -45,6 +45,7 @@ static HeadWs carve(void* base, int64_t N, int64_t way, int64_t shot, int64_t K,
     TAKE(dpool, NB * C);
     TAKE(u2, B * C);
     TAKE(u3, B * C);
+    TAKE(coef, B * C);                       // large batches: coefficients of the chunked dFs writer
 #undef TAKE
     s.total = off * 4;
     return s;
@@ -134,6 +135,10 @@ static inline bool bwd_dfq_nt(int64_t N, int64_t C, int64_t P, size_t sF) {
 static inline bool dfs_nt(int64_t B, int64_t C, int64_t P, size_t sF) {
     return B * C * P * (int64_t)sF > ((int64_t)DENET_DFS_NT_MB << 20);
 }
+#ifndef DENET_DFS_CHUNKED
+#define DENET_DFS_CHUNKED 1
+#endif
+static inline bool dfs_chunked(bool nt, bool f32) { return DENET_DFS_CHUNKED && nt && !f32; }
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
@@ -245,8 +250,9 @@ extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_
     p.bwd_groups = p.bwd_persistent ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
     p.bwd_dfq_nt = p.bwd_persistent && bwd_dfq_nt(N, C, P, sF);
     p.dfs_nt = dfs_nt(B, C, P, sF);
-    // (dev_masked_sum.hpp, masked_sum_bwd_body: ROWS = !NT || bf16)
-    p.dfs_flat_writer = p.dfs_nt && !(sF == 2 && DENET_NT_BF16_ROWS);
+    // non-temporal streams: fp32 = the flat span writer inside B3, bf16 = coefficient blocks + dfs_chunk_kernel
+    p.dfs_chunked = dfs_chunked(p.dfs_nt, sF == 4);
+    p.dfs_flat_writer = p.dfs_nt && sF == 4;
     *out = p;
     return DENET_OK;
 }
@@ -418,7 +424,15 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
     }
     // B3: parameter gradients || coef + dFs
     {
-        CoefArgs ca{s.dh_part, s.hidden, W1, s.dpool, s.gate, s.cnt, (int)shot, (int)(C / 16), (float)P, SC_EPS};
+        const bool nt = dfs_nt(B, C, P, f32 ? 4 : 2);
+        // bf16 streams that go around the caches are written by a kernel of their own, one block per contiguous
+        // chunk in address order (dev_masked_sum.hpp: dfs_chunk_kernel); the dFs blocks of this launch then only
+        // compute their slice's coefficients.  C5 (269 MB): B3 86.1 -> 60.6 us, step 396 -> 371 us.  fp32 keeps the
+        // flat span writer inside this launch: chunked it measured 86.4 vs 82.7 us at C3 (344 MB) and 332 vs 284 us
+        // at 1.1 GB (one short-lived thread per 16 bytes: the mask load's latency is not hidden).
+        const bool chunked = dfs_chunked(nt, f32) && ((uintptr_t)dFs & 15) == 0 && C * P < (1 << 22) && B <= 65535;
+        CoefArgs ca{s.dh_part, s.hidden, W1, s.dpool, s.gate, s.cnt, (int)shot, (int)(C / 16), (float)P, SC_EPS,
+                    chunked ? s.coef : nullptr};
         // one launch, or its two halves apart (DENET_BWD_NO_DFS / DENET_BWD_ONLY_DFS): the kernel takes
         // its first gridDim.x - 3*gx blocks as dFs blocks
         const int gx = only_dfs ? 0 : (int)C / WG_ROWS;      // blocks of each of the roles dW1, dW2, dWl
@@ -427,12 +441,14 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         dim3 grid((unsigned)(3 * gx + ndfs)), block(256);
         const bool on = probe && probe->which == DENET_K_MASKED_SUM_BWD && probe->start && probe->stop;
         if (on && hipEventRecord((hipEvent_t)probe->start, st) != hipSuccess) return DENET_E_LAUNCH;
-        const bool nt = dfs_nt(B, C, P, f32 ? 4 : 2);
         // LDS: the mask image of the dFs blocks (dev_masked_sum.hpp) + their 64 + 16 floats
         size_t lds = (size_t)((f32 ? (nt ? mask_image_floats<4, MaskImage<float, true>::PLANAR>((int)P)
                                          : mask_image_floats<4, MaskImage<float, false>::PLANAR>((int)P))
                                    : mask_image_floats<8, true>((int)P)) + 64 + 16) * 4;
         if (lds < 4096) lds = 4096;
+#ifdef DENET_TAIL_LDS_MIN_NT
+        if (nt && lds < (size_t)DENET_TAIL_LDS_MIN_NT) lds = (size_t)DENET_TAIL_LDS_MIN_NT;   // diagnostic: fewer resident blocks
+#endif
 #define TAIL_GO(TT, NSLT)                                                                                           \
     if (nt) {                                                                                                       \
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, true>), lds))     \
@@ -452,6 +468,28 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         }
 #undef TAIL_GO
         DENET_CHECK_LAUNCH();
+        if (chunked && !no_dfs) {
+#ifndef DENET_DFS_CHUNK_U_F32
+#define DENET_DFS_CHUNK_U_F32 2
+#endif
+#ifndef DENET_DFS_CHUNK_U_BF16
+#define DENET_DFS_CHUNK_U_BF16 2
+#endif
+            const int64_t span = C * P;
+            if (f32) {
+                constexpr int U = DENET_DFS_CHUNK_U_F32;
+                const int64_t per = 256 * U * 4;
+                hipLaunchKernelGGL((dfs_chunk_kernel<float, U>), dim3((unsigned)((span + per - 1) / per), (unsigned)B),
+                                   dim3(256), 0, st, s.mask, s.coef, (float*)dFs, (int)C, (int)P);
+            } else {
+                constexpr int U = DENET_DFS_CHUNK_U_BF16;
+                const int64_t per = 256 * U * 8;
+                hipLaunchKernelGGL((dfs_chunk_kernel<unsigned short, U>),
+                                   dim3((unsigned)((span + per - 1) / per), (unsigned)B), dim3(256), 0, st, s.mask, s.coef,
+                                   (unsigned short*)dFs, (int)C, (int)P);
+            }
+            DENET_CHECK_LAUNCH();
+        }
         if (on && hipEventRecord((hipEvent_t)probe->stop, st) != hipSuccess) return DENET_E_LAUNCH;
     }
     return DENET_OK;

@@ -135,7 +135,7 @@ static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float*
     // vector and plane, so its MASK_TAIL covers that; the row-major fp32 image holds four, and those reads land
     // in the parked W1 slices -- or, without them (stand-alone call), in 3072 floats of padding
     const bool rowmajor = f32 && longr && !MaskImage<float, false>::PLANAR;
-    const size_t lds = (size_t)((f32 ? (longr ? mask_image_floats<4, MaskImage<float, false>::PLANAR>(P)
+    size_t lds = (size_t)((f32 ? (longr ? mask_image_floats<4, MaskImage<float, false>::PLANAR>(P)
                                           : mask_image_floats<4, MaskImage<float, true>::PLANAR>(P))
                                    : mask_image_floats<8, true>(P)) + 4 + 16) * 4 +
                        (W1 ? 256 * 64 : (rowmajor ? 3072 * 4 : 0));
@@ -151,6 +151,9 @@ static int launch_pool(const void* Fs, int feat_dtype, const int64_t* Ys, float*
         if (ntl) POOL_GO2(TT, LG, true); else POOL_GO2(TT, LG, false);                                            \
     } while (0)
     const bool ntl = pl.nt_loads;
+#ifdef DENET_POOL_LDS_MIN_NTL
+    if (ntl && lds < (size_t)DENET_POOL_LDS_MIN_NTL) lds = (size_t)DENET_POOL_LDS_MIN_NTL;        // diagnostic: fewer resident blocks
+#endif
     if (f32) {
         if (longr) POOL_GO(float, true); else POOL_GO(float, false);
     } else {
@@ -195,6 +198,30 @@ extern "C" int denet_masked_sum_bwd(const float* mask, const float* coef, int64_
             return DENET_E_LAUNCH;
         hipLaunchKernelGGL(masked_sum_bwd_kernel<unsigned short>, grid, dim3(256), lds, (hipStream_t)stream, mask,
                            coef, (unsigned short*)dFs, (int)C, (int)P, rpb);
+    } else {
+        return DENET_E_UNSUPPORTED;
+    }
+    DENET_CHECK_LAUNCH();
+    return DENET_OK;
+}
+
+// K1b for large streams: the same dFs = mask x coef written by dfs_chunk_kernel (one block per contiguous chunk of
+// the flat tensor, in address order, non-temporal stores) -- what the fused step runs for bf16 streams above 80 MB.
+// Same arguments and results as denet_masked_sum_bwd; dFs must be 16-byte aligned, C a multiple of 64.
+extern "C" int denet_masked_sum_bwd_chunked(const float* mask, const float* coef, int64_t B, int64_t C, int64_t P,
+                                            void* dFs, int feat_dtype, void* stream) {
+    if (!dFs || !mask || !coef) return DENET_E_BADARG;
+    if (!fits_int(B) || !fits_int(C) || !fits_int(P)) return DENET_E_BADARG;
+    if (P < 4 || (C & 63) || C * P >= (1 << 22) || B > 65535 || ((uintptr_t)dFs & 15)) return DENET_E_UNSUPPORTED;
+    const int64_t span = C * P;
+    if (feat_dtype == DENET_F32) {
+        const int64_t per = 256 * 2 * 4;
+        hipLaunchKernelGGL((dfs_chunk_kernel<float, 2>), dim3((unsigned)((span + per - 1) / per), (unsigned)B), dim3(256),
+                           0, (hipStream_t)stream, mask, coef, (float*)dFs, (int)C, (int)P);
+    } else if (feat_dtype == DENET_BF16) {
+        const int64_t per = 256 * 2 * 8;
+        hipLaunchKernelGGL((dfs_chunk_kernel<unsigned short, 2>), dim3((unsigned)((span + per - 1) / per), (unsigned)B),
+                           dim3(256), 0, (hipStream_t)stream, mask, coef, (unsigned short*)dFs, (int)C, (int)P);
     } else {
         return DENET_E_UNSUPPORTED;
     }

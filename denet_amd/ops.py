@@ -60,10 +60,12 @@ def masked_pool(Fs: torch.Tensor, Ys: torch.Tensor):
     return mask, cnt, S
 
 
-def masked_sum_bwd(mask, coef, shape, dtype):
+def masked_sum_bwd(mask, coef, shape, dtype, chunked=False):
+    """dFs = mask x coef (K1b).  chunked: the large-stream writer (denet_masked_sum_bwd_chunked), same results."""
     B, C, h, w = shape
     dFs = torch.empty(B, C, h, w, dtype=dtype, device=mask.device)
-    call("denet_masked_sum_bwd", mask, coef, B, C, h * w, dFs, feat_code(dFs))
+    call("denet_masked_sum_bwd_chunked" if chunked else "denet_masked_sum_bwd", mask, coef, B, C, h * w, dFs,
+         feat_code(dFs))
     return dFs
 
 

@@ -65,6 +65,11 @@ int denet_masked_pool_fwd(const void* Fs, int feat_dtype, const int64_t* Ys, int
  *   dFs[b,c,p] = mask[b,p] * coef[b,c]     (rank-1; Fs itself is not re-read) */
 int denet_masked_sum_bwd(const float* mask, const float* coef /*[B,C]*/, int64_t B, int64_t C,
                          int64_t P, void* dFs, int feat_dtype, void* stream);
+/* The same operation (same reference lines, bit-identical results) for large streams: one block per contiguous
+ * chunk of the flat dFs tensor, in address order, non-temporal stores -- the write pattern of a fill kernel.  The
+ * fused step uses it for bf16 gradients above 80 MB.  dFs 16-byte aligned, C a multiple of 64, C*P < 2^22. */
+int denet_masked_sum_bwd_chunked(const float* mask, const float* coef /*[B,C]*/, int64_t B, int64_t C,
+                                 int64_t P, void* dFs, int feat_dtype, void* stream);
 
 /* ---- K2: gate, projection, dynamic extension ----------------------------
  * Replaces GAM.gate (model/common.py:225-232,244), MaskedAveragePooling's
@@ -295,8 +300,10 @@ typedef struct denet_step_plan {
     int32_t bwd_groups;       /* dWn slabs per episode written by B1                                         */
     int32_t bwd_dfq_nt;       /* dFq leaves B1 with non-temporal stores                                      */
     int32_t dfs_nt;           /* dFs leaves B3 with non-temporal stores                                      */
-    int32_t dfs_flat_writer;  /* B3 writes the block's 16 rows as one span (fp32 + NT) instead of a row per wave */
-    int32_t reserved[3];
+    int32_t dfs_flat_writer;  /* fp32 + dfs_nt: B3 writes the block's 16 rows as one span instead of a row per wave */
+    int32_t dfs_chunked;      /* bf16 + dfs_nt: B3's blocks only form coefficients, a second launch writes the flat
+                                 tensor one contiguous chunk per block, in address order                              */
+    int32_t reserved[2];
 } denet_step_plan_t;
 int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                          int64_t H, int64_t W, int feat_dtype, denet_step_plan_t* out);

@@ -272,3 +272,21 @@ def test_loss_kernel_extreme_logits(geom, dev):
     assert rel_err(loss.cpu(), ref.detach()) < 1e-5
     assert rel_err(per_dev.cpu(), torch.stack(per).detach()) < 1e-5
     assert rel_err(dl.cpu(), ref_in.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,h,w", [(3, 64, 5, 7), (2, 256, 41, 41), (5, 64, 9, 9), (1, 64, 2, 2), (2, 128, 33, 31)])
+def test_chunked_dfs_writer_equals_the_row_writer(dev, dtype, B, C, h, w):
+    """K1b's two writers: dFs = mask x coef by rows (denet_masked_sum_bwd) and by contiguous chunks of the flat
+    tensor (denet_masked_sum_bwd_chunked, the fused step's writer for large bf16 streams): bit-identical, on shapes
+    whose rows straddle the 16-byte vectors in every phase (odd P), whose last chunk is partial, and on a span
+    shorter than one chunk; and both equal the product itself."""
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + h)
+    mask = (torch.rand(B, h * w, generator=g) > 0.3).float().to(dev)
+    coef = torch.randn(B, C, generator=g).to(dev)
+    a = ops.masked_sum_bwd(mask, coef, (B, C, h, w), dtype)
+    b = ops.masked_sum_bwd(mask, coef, (B, C, h, w), dtype, chunked=True)
+    assert torch.equal(a, b)
+    ref = (coef.unsqueeze(2) * mask.unsqueeze(1)).reshape(B, C, h, w).to(dtype)
+    assert torch.equal(b, ref)
