@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = [("wce_chain_pair_kernel", "loss_pair_fwd"), ("upsample_loss_pair_kernel", "loss_pair_fwd"),
          ("wce_chain_kernel", "wce_fwd"), ("focal_kernel", "focal_fwd"), ("classify_fwd_wide4_kernel", "classify_fwd"), ("classify_fwd_wide_kernel", "classify_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"), ("head_bwd_dwn_wide_kernel", "bwd_dwn"),
          ("head_bwd_mid_kernel", "bwd_chain_dfq"), ("head_bwd_tail_kernel", "bwd_params_dfs"),
-         ("mask_resize_flat_kernel", "mask_resize"), ("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_pool_fwd"),
+         ("dfs_chunk_kernel", "dfs_chunk"), ("mask_resize_flat_kernel", "mask_resize"), ("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_pool_fwd"),
          ("proto_extend_fwd_kernel", "proto_extend_fwd"), ("gate_proj_kernel", "proto_extend_fwd"), ("classify_fwd_kernel", "classify_fwd"),
          ("upsample_loss_kernel<0, true>", "wce_fwd"), ("upsample_loss_kernel<0, false>", "wce_fwd_nograd"),
          ("upsample_loss_kernel<1, false>", "focal_fwd"), ("loss_finalize_kernel", "loss_finalize"),
@@ -46,7 +46,7 @@ NAMES = [("wce_chain_pair_kernel", "loss_pair_fwd"), ("upsample_loss_pair_kernel
 #    8 B/lane: classify_fwd (Fq pairs), loss_pair_fwd / wce_fwd / focal_fwd (int64 labels), mask_resize
 #    4 B/lane: bwd_chain_dfq (slab rows), bwd_params_dfs (mask rows; its 80 MB are WRITES)
 LOAD_WIDTH = {"masked_pool_fwd": 16, "masked_sum_bwd": 16, "pe_bwd_reduce": 16, "proto_extend_fwd": 16,
-              "bwd_dwn": 16, "classify_bwd": 16,
+              "bwd_dwn": 16, "classify_bwd": 16, "dfs_chunk": 16,
               "classify_fwd": 8, "loss_pair_fwd": 8, "wce_fwd": 8, "focal_fwd": 8, "wce_fwd_nograd": 8, "mask_resize": 8,
               "bwd_chain_dfq": 4, "bwd_params_dfs": 4, "loss_finalize": 4}
 WIDTH_FACTOR = {4: 1.0, 8: 1.0, 16: 2.0}          # overwritten from profiles/r2_fetch_calibration.json if present
@@ -98,8 +98,10 @@ def main():
     ap.add_argument("write_dir", nargs="?")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--episodes", type=int, default=8)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"),
+                    help="where to write (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)")
     a = ap.parse_args()
-    out = os.path.join(ROOT, "profiles")
+    out = a.out
     os.makedirs(out, exist_ok=True)
     stats = find(a.stats_dir, "*kernel_stats.csv")
     lines = []
@@ -116,7 +118,8 @@ def main():
         load_calibration()
         fe, wr = pmc_mean(a.fetch_dir, "FETCH_SIZE"), pmc_mean(a.write_dir, "WRITE_SIZE")
         path = os.path.join(out, "pmc_traffic.json")
-        allruns = json.load(open(path)) if os.path.exists(path) else {}
+        seed = path if os.path.exists(path) else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        allruns = json.load(open(seed)) if os.path.exists(seed) else {}
         if "runs" not in allruns:
             allruns = {"runs": {}}
         allruns["note"] = ("hbm_bytes_per_launch = f*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB counters, separate --pmc "

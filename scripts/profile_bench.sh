@@ -10,4 +10,6 @@ ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-dropin --no-rotating --prob
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py $ARGS > gpurun_out/${tag}_stats.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python3 bench.py $ARGS > gpurun_out/${tag}_fetch.log 2>&1 || exit 2
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- python3 bench.py $ARGS > gpurun_out/${tag}_write.log 2>&1 || exit 3
+# the per-dispatch trace is megabytes per run and gpurun copies back at most 64 MiB: keep the stats table only
+find gpurun_out/${tag}_stats -name "*_kernel_trace.csv" -delete
 ls gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write
