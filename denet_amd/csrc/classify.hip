@@ -19,10 +19,96 @@
 //     are summed through LDS in a fixed order (deterministic), which gives
 //     N * ceil(P/64) * 4 waves of parallelism at batch 8.
 // fp32 in, fp32 accumulate: bit-for-bit an fmaf chain per output (guide §3).
+#include <type_traits>
+
 #include "denet_common.hpp"
 #include "dev_classify.hpp"
 
 #include "dev_classify_fwd.hpp"
+
+// Epilogue of the wave-per-tile kernels: logits from the accumulators (C/D layout of the 32x32 MFMAs: column =
+// lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), then the binary logits.
+template <int RT>
+__device__ __forceinline__ void wide4_epilogue(f32x16 (&acc)[RT][2], const int64_t* __restrict__ labels, int way, int K,
+                                               int P, int base, float* __restrict__ logits, float* __restrict__ bin,
+                                               int n, int pa, int j, int hh) {
+    // ---- logits: straight from the accumulators ----
+    float* lg = logits + (int64_t)n * K * P;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (row < K) {
+                float* dst = lg + (int64_t)row * P + pa;
+                if (pa + 1 < P) *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{acc[rt][0][e], acc[rt][1][e]};
+                else if (pa < P) dst[0] = acc[rt][0][e];
+            }
+        }
+    if (bin == nullptr) return;
+
+    // ---- binary logits (utils/operations.py:327-337) ----
+    // per lane and position: the largest and the second largest entry over this lane's rows (ties count: two
+    // equal maxima give m2 == m1), then merged across the two lane halves.  max over k != lab is then
+    // m2 if the label row holds the maximum (fg == m1), else m1 -- no row index needed.
+    float m1[2] = {-INFINITY, -INFINITY}, m2[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = row < K ? acc[rt][t][e] : -INFINITY;
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);       // second largest of {m1 >= m2, v}
+                m1[t] = fmaxf(m1[t], v);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float o1 = __shfl_xor(m1[t], 32, 64), o2 = __shfl_xor(m2[t], 32, 64);
+        const float hi = fmaxf(m1[t], o1), lo = fminf(m1[t], o1);
+        m2[t] = fmaxf(lo, fmaxf(m2[t], o2));
+        m1[t] = hi;
+    }
+    for (int jw = 0; jw < way; ++jw) {
+        const int64_t lab64 = labels[(int64_t)n * way + jw];
+        const bool labok = lab64 >= 0 && lab64 < K;
+        const int lab = labok ? (int)lab64 : 0;
+        // the accumulator that holds row `sel`: (rt, e) are wave-uniform, the lane half is (row >> 2) & 1
+        auto pick = [&](int sel, float (&out)[2]) {
+            const int r = sel & 31, idx = (sel >> 5) * 16 + (r & 3) + 4 * (r >> 3), half = (r >> 2) & 1;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (idx == rt * 16 + e) { v0 = acc[rt][0][e]; v1 = acc[rt][1][e]; }     // uniform branch
+            const float w0 = __shfl_xor(v0, 32, 64), w1 = __shfl_xor(v1, 32, 64);
+            out[0] = hh == half ? v0 : w0;
+            out[1] = hh == half ? v1 : w1;
+        };
+        float fg[2], outb[2];
+        pick(lab, fg);
+        if (base) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) outb[t] = (labok && fg[t] == m1[t]) ? m2[t] : m1[t];
+        } else {
+            pick(0, outb);
+        }
+        if (hh == 0) {
+            float* dst = bin + ((int64_t)(n * way + jw) * 2) * P + pa;
+            const float f0 = labok ? fg[0] : 0.f, f1 = labok ? fg[1] : 0.f;
+            if (pa + 1 < P) {
+                *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{outb[0], outb[1]};
+                *reinterpret_cast<f32x2_u*>(dst + P) = f32x2_u{f0, f1};
+            } else if (pa < P) {
+                dst[0] = outb[0];
+                dst[P] = f0;
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // K > 32 (COCO: K = 81): Wn[n] is 83 KB of LDS, one block per CU, and the layout above re-stages it for every
@@ -124,84 +210,174 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __rest
     }
 
     STAMP(2);
-    // ---- logits: straight from the accumulators ----
-    float* lg = logits + (int64_t)n * K * P;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (row < K) {
-                float* dst = lg + (int64_t)row * P + pa;
-                if (pa + 1 < P) *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{acc[rt][0][e], acc[rt][1][e]};
-                else if (pa < P) dst[0] = acc[rt][0][e];
-            }
-        }
-    STAMP(3);
-    if (bin == nullptr) return;
+    wide4_epilogue<RT>(acc, labels, way, K, P, base, logits, bin, n, pa, j, hh);
+    STAMP(4);
+}
 
-    // ---- binary logits (utils/operations.py:327-337) ----
-    // per lane and position: the largest and the second largest entry over this lane's rows (ties count: two
-    // equal maxima give m2 == m1), then merged across the two lane halves.  max over k != lab is then
-    // m2 if the label row holds the maximum (fg == m1), else m1 -- no row index needed.
-    float m1[2] = {-INFINITY, -INFINITY}, m2[2] = {-INFINITY, -INFINITY};
+// ---------------------------------------------------------------------------
+// bf16 features, K <= 96: the same block shape (a wave per 64-position tile, four tiles per block, Wn[n] resident
+// in LDS) on the bf16 matrix pipe, v_mfma_f32_32x32x16_bf16 = 16x the rate of the fp32 instruction.  The streamed
+// operand is bf16 already; the fp32 class weights are split into three bf16 planes, hi + mid + lo = the fp32
+// value EXACTLY (8 + 8 + 8 significand bits, truncating splits), so every product bf16 x bf16 is exact in fp32
+// and the result differs from the fp32-MFMA kernel only in the order of the fp32 additions:
+//   logits = sum_c (hi + mid + lo)[k][c] * Fq[c][p]          3 MFMAs of 16 channels instead of 8 of 2.
+// Matrix work per SIMD at K = 81, C = 256: 288 MFMAs x 32 cycles = 9.2 k cycles against 768 x 64 = 49 k, which
+// leaves the kernel bound by its loads -- so ALL of the wave's Fq (C/2 dwords per lane: 8 channels x 2 adjacent
+// positions per 16-channel k-step) is requested right after the Wn loads have landed in LDS and arrives under the
+// plane conversion; the MFMA loop consumes the k-steps as their loads retire.
+//   A operand (Wn planes): lane (r = lane & 31, h = lane >> 5) holds row r, channels c0 + 8h .. 8h+7 = one
+//     ds_read_b128 of plane[s][32 rt + r]; plane rows are C + 8 bf16 (528 B: 16 lanes x 16 B cover the 64 banks).
+//   B operand (Fq): the same lane holds channels c0 + 8h + i of column r; the dword loaded for channel i carries
+//     positions pa (low half) and pa + 1 (high half) = column r of tile 0 and of tile 1, so two v_perm_b32 per
+//     channel pair build both tiles' fragments.
+// LDS: 3 x 32 RT x (C + 8) x 2 B = 152 KB at RT = 3 (the fp32 image is staged first in the same bytes and
+// converted through registers).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// w = hi + mid + lo, each a bf16 (returned in the high half of a dword); exact for finite w
+__device__ __forceinline__ void split_bf16x3(float w, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(h);               // <= 16 significant bits
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);              // <= 8 significant bits
+    l = __float_as_uint(r2) & 0xffff0000u;
+}
+
+#define CLB_LDS(RT, C) ((size_t)3 * 32 * (RT) * ((C) + 8) * 2)
+template <int RT, bool BUILD, int CJ>
+__global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsigned short* __restrict__ Fq,
+                                                                    const float* __restrict__ Wn, int64_t wn_stride,
+                                                                    const int64_t* __restrict__ labels, int way, int K,
+                                                                    int P, int base, float* __restrict__ logits,
+                                                                    float* __restrict__ bin, WnBuild wb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = 64 * CJ, NR = 32 * RT;
+    constexpr int KS = C / 16;                     // k-steps of 16 channels
+    constexpr int LDD = (C + 8) / 2;               // dwords per plane row
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ldw = C + 1;
+    const int ntile = (P + CL_TP - 1) / CL_TP;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool active = tile < ntile;
+    const int p0 = (active ? tile : ntile - 1) * CL_TP;
+    const int pa = p0 + 2 * j;
+    const int pc = max(min(pa, P - 2), 0), sh = pa - pc;
+    const unsigned short* fq = Fq + (int64_t)n * C * P;
+
+    STAMP(0);
+    // Wn first (L2 hits, back in a round trip), THEN the Fq requests: vmcnt retires in order, so a wait on Wn
+    // behind 128 HBM loads would be a wait on all of them; this way the conversion below runs under the Fq stream
+    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : 24;
+    stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
+    for (int i = K * ldw + tid; i < NR * ldw; i += 256) sm[i] = 0.f;           // zero rows K .. 32 RT - 1
+    STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // the wave's B operand: channel 16 q + 8 hh + i, positions pc, pc + 1 (unconditional, clamped), requested in
+    // two halves -- a wave keeps ~64 loads in flight, so asking for all C/2 at once stalls the issue for a round
+    // trip (3.5 us measured) before the conversion can start; the second half goes out after it, under the
+    // first half's MFMAs
+    unsigned x[KS][8];
+    auto request = [&](int q0, int q1) {
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#ifdef DENET_DIAG_NO_FQ
+                x[q][i] = 0u;
+#else
+                x[q][i] = raw2_load(fq + (unsigned)(16 * q + 8 * hh + i) * (unsigned)P, pc);      // C * P < 2^31
+#endif
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int KH = KS > 4 ? KS / 2 : KS;
+    request(0, KH);
+    STAMP(2);
+
+    __syncthreads();
+    STAMP(3);
+    if constexpr (BUILD) {
+        float* dst = wb.Wn_out + (int64_t)n * K * C;
+        for (int k = blockIdx.x; k < K; k += gridDim.x)
+            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
+    }
+    // ---- fp32 image [NR][C + 1] -> bf16 planes [3][NR][C + 8], in place through registers ----
+    {
+        constexpr int PER = NR * (C / 2) / 256;    // channel pairs per thread (48 at RT = 3, C = 256)
+        float v0[PER], v1[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
+            v0[q] = sm[row * ldw + 2 * cp];
+            v1[q] = sm[row * ldw + 2 * cp + 1];
+        }
+        __syncthreads();
+        unsigned* pl = reinterpret_cast<unsigned*>(sm);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_bf16x3(v0[q], h0, m0, l0);
+            split_bf16x3(v1[q], h1, m1, l1);
+            pl[(0 * NR + row) * LDD + cp] = (h0 >> 16) | h1;
+            pl[(1 * NR + row) * LDD + cp] = (m0 >> 16) | m1;
+            pl[(2 * NR + row) * LDD + cp] = (l0 >> 16) | l1;
+        }
+        __syncthreads();
+    }
+    request(KH, KS);
+    if (!active) return;                           // (no barrier below this line)
+    STAMP(4);
+
+    f32x16 acc[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float v = row < K ? acc[rt][t][e] : -INFINITY;
-                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);       // second largest of {m1 >= m2, v}
-                m1[t] = fmaxf(m1[t], v);
-            }
-        }
+            for (int e = 0; e < 16; ++e) acc[rt][t][e] = 0.f;
+    const unsigned* pla = reinterpret_cast<const unsigned*>(sm) + j * LDD + 4 * hh;
+    // A fragments one k-step ahead of their MFMAs (one wave per SIMD: an LDS read issued right before its MFMA
+    // exposes its latency every time)
+    u32x4 af[2][3 * RT];
+    auto load_a = [&](int q, u32x4 (&a)[3 * RT]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float o1 = __shfl_xor(m1[t], 32, 64), o2 = __shfl_xor(m2[t], 32, 64);
-        const float hi = fmaxf(m1[t], o1), lo = fminf(m1[t], o1);
-        m2[t] = fmaxf(lo, fmaxf(m2[t], o2));
-        m1[t] = hi;
-    }
-    for (int jw = 0; jw < way; ++jw) {
-        const int64_t lab64 = labels[(int64_t)n * way + jw];
-        const bool labok = lab64 >= 0 && lab64 < K;
-        const int lab = labok ? (int)lab64 : 0;
-        // the accumulator that holds row `sel`: (rt, e) are wave-uniform, the lane half is (row >> 2) & 1
-        auto pick = [&](int sel, float (&out)[2]) {
-            const int r = sel & 31, idx = (sel >> 5) * 16 + (r & 3) + 4 * (r >> 3), half = (r >> 2) & 1;
-            float v0 = 0.f, v1 = 0.f;
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
+                a[s * RT + rt] = *reinterpret_cast<const u32x4*>(pla + (s * NR + 32 * rt) * LDD + 8 * q);
+    };
+    load_a(0, af[0]);
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (idx == rt * 16 + e) { v0 = acc[rt][0][e]; v1 = acc[rt][1][e]; }     // uniform branch
-            const float w0 = __shfl_xor(v0, 32, 64), w1 = __shfl_xor(v1, 32, 64);
-            out[0] = hh == half ? v0 : w0;
-            out[1] = hh == half ? v1 : w1;
-        };
-        float fg[2], outb[2];
-        pick(lab, fg);
-        if (base) {
+    for (int q = 0; q < KS; ++q) {
+        if (q + 1 < KS) load_a(q + 1, af[(q + 1) & 1]);
+        u32x4 b0, b1;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) outb[t] = (labok && fg[t] == m1[t]) ? m2[t] : m1[t];
-        } else {
-            pick(0, outb);
+        for (int m = 0; m < 4; ++m) {
+            const unsigned lo = __builtin_amdgcn_perm(x[q][2 * m + 1], x[q][2 * m], 0x05040100u);   // positions pc
+            const unsigned hi = __builtin_amdgcn_perm(x[q][2 * m + 1], x[q][2 * m], 0x07060302u);   // positions pc + 1
+            b0[m] = sh == 1 ? hi : lo;             // sh == 1: the last position of an odd P sits in the high half
+            b1[m] = hi;
         }
-        if (hh == 0) {
-            float* dst = bin + ((int64_t)(n * way + jw) * 2) * P + pa;
-            const float f0 = labok ? fg[0] : 0.f, f1 = labok ? fg[1] : 0.f;
-            if (pa + 1 < P) {
-                *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{outb[0], outb[1]};
-                *reinterpret_cast<f32x2_u*>(dst + P) = f32x2_u{f0, f1};
-            } else if (pa < P) {
-                dst[0] = outb[0];
-                dst[P] = f0;
+        const bf16x8 B0 = __builtin_bit_cast(bf16x8, b0), B1 = __builtin_bit_cast(bf16x8, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 A = __builtin_bit_cast(bf16x8, af[q & 1][s * RT + rt]);
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B1, acc[rt][1], 0, 0, 0);
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    STAMP(4);
+    STAMP(5);
+    wide4_epilogue<RT>(acc, labels, way, K, P, base, logits, bin, n, pa, j, hh);
+    STAMP(6);
 }
 
 // K > 32: the MFMA work of an episode is spread over as many CUs as there are (one block per CU: Wn[n] takes
@@ -453,10 +629,15 @@ static int set_lds(KernelT kern, size_t lds) {
 }
 
 // Forward layout for a shape (also reported by denet_head_step_plan): DENET_CLS_TILE8 = eight waves per
-// 64-position tile (K <= 32, few tiles), DENET_CLS_UNITS = layout (a) below, DENET_CLS_WAVE4 = layout (b).
+// 64-position tile (K <= 32, few tiles), DENET_CLS_UNITS = layout (a) below, DENET_CLS_WAVE4 = layout (b),
+// DENET_CLS_WAVE4_BF16 = layout (b) on the bf16 matrix pipe (bf16 features, 32 < K <= 96).
 // `groups` (layout (a): blocks per episode) is returned through the pointer when it is not null.
-int denet_classify_fwd_layout(int64_t N, int64_t K, int64_t P, int64_t* groups_out) {
+int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, int64_t* groups_out) {
     const int RT = (int)((K + 31) / 32);
+    if (groups_out) *groups_out = 0;
+    // bf16 features: the split-weight bf16 MFMA kernel wherever Wn[n] stays resident (its three planes fit in
+    // LDS up to K = 96); its matrix work is a fifth of the fp32 instruction's, so the unit layout has nothing to win
+    if (feat_dtype == DENET_BF16 && (RT == 2 || RT == 3)) return DENET_CLS_WAVE4_BF16;
     // K <= 32 with many tiles: layout (b) (a wave per tile, Wn staged once per four tiles) instead of the
     // latency-oriented eight-waves-per-tile kernel
     // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
@@ -484,7 +665,30 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
                                hipStream_t st, WnBuild wb = WnBuild{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int RT = (int)((K + 31) / 32);
     int64_t groups = 0;
-    const int layout = denet_classify_fwd_layout(N, K, P, &groups);
+    const int layout =
+        denet_classify_fwd_layout(std::is_same<T, unsigned short>::value ? DENET_BF16 : DENET_F32, N, K, P, &groups);
+    if (layout == DENET_CLS_WAVE4_BF16) {
+        if constexpr (std::is_same<T, unsigned short>::value) {
+            const size_t ldsb = CLB_LDS(RT, C);
+            if (ldsb > 160 * 1024) return DENET_E_UNSUPPORTED;
+            const int ntile = (int)((P + CL_TP - 1) / CL_TP);
+            dim3 gridb((unsigned)((ntile + 3) / 4), (unsigned)N), blockb(256);
+#define CL_WIDE4B(R, J)                                                                                       \
+    {                                                                                                         \
+        int rc = set_lds(classify_fwd_wide4_bf16_kernel<R, BUILD, J>, ldsb);                                  \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((classify_fwd_wide4_bf16_kernel<R, BUILD, J>), gridb, blockb, ldsb, st, Fq, Wn, wn_stride, \
+                           labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
+    }
+            if (RT == 2) { if (C == 64) CL_WIDE4B(2, 1) else CL_WIDE4B(2, 4) }
+            else { if (C == 64) CL_WIDE4B(3, 1) else CL_WIDE4B(3, 4) }
+#undef CL_WIDE4B
+            DENET_CHECK_LAUNCH();
+            return DENET_OK;
+        } else {
+            return DENET_E_UNSUPPORTED;
+        }
+    }
     if (layout != DENET_CLS_TILE8) {
         const bool by_units = layout == DENET_CLS_UNITS;
         if (!by_units) {

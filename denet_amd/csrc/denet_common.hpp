@@ -9,7 +9,7 @@
 // ---- launcher decisions shared between the translation units (reported by denet_head_step_plan) ----
 struct PoolPlan { bool two_launch, long_rows, nt_loads; };
 PoolPlan denet_pool_plan(int feat_dtype, int64_t B, int64_t C, int64_t P, bool fused);          // masked_sum.hip
-int denet_classify_fwd_layout(int64_t N, int64_t K, int64_t P, int64_t* groups_out);            // classify.hip
+int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, int64_t* groups_out);            // classify.hip
 struct LossPlan { int chain_cell, chunk, xsplit, rsplit; };
 bool denet_loss_plan(int64_t K, int64_t h, int64_t w, int64_t H, int64_t W, bool grad, LossPlan* out);  // upsample_loss.hip
 

@@ -239,7 +239,7 @@ extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_
     p.pool_long_rows = pl.long_rows;
     p.pool_nt_loads = pl.nt_loads;
     int64_t groups = 0;
-    p.classify_layout = denet_classify_fwd_layout(N, K, P, &groups);
+    p.classify_layout = denet_classify_fwd_layout(feat_dtype, N, K, P, &groups);
     p.classify_groups = p.classify_layout == DENET_CLS_UNITS ? (int32_t)groups : 0;
     LossPlan lp;
     if (!denet_loss_plan(K, h, w, H, W, true, &lp)) return DENET_E_UNSUPPORTED;

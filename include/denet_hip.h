@@ -287,6 +287,8 @@ int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t 
 #define DENET_CLS_TILE8   0   /* eight waves per 64-position tile (K <= 32, < 384 tiles in the batch) */
 #define DENET_CLS_UNITS   1   /* K > 32: (half tile, row tile) units dealt to eight waves             */
 #define DENET_CLS_WAVE4   2   /* a wave per tile, four tiles per block                                 */
+#define DENET_CLS_WAVE4_BF16 3 /* bf16 features, 32 < K <= 96: the same block shape on the bf16 matrix pipe,
+                                  class weights split into three bf16 planes (exact)                    */
 typedef struct denet_step_plan {
     int32_t pool_launches;    /* 1: mask gathered inside the pooling kernel; 2: flat mask resize first       */
     int32_t pool_long_rows;   /* rolling-loop pooling kernel (rows of more than 512 16-byte vectors)         */

@@ -9,6 +9,7 @@ int denet_ensure_dynamic_lds(const void* kernel, size_t bytes) {
 }
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 8, way = argc > 2 ? atoi(argv[2]) : 1, K = argc > 3 ? atoi(argv[3]) : 21, C = 256, P = argc > 4 ? atoi(argv[4]) : 1681;
+    const int dt = argc > 5 && atoi(argv[5]) ? DENET_BF16 : DENET_F32;
     float *Fq, *Wn, *logits, *bin; int64_t* labels;
     CK(hipMalloc(&Fq, (size_t)N * C * P * 4)); CK(hipMalloc(&Wn, N * K * C * 4)); CK(hipMalloc(&logits, N * K * P * 4));
     CK(hipMalloc(&bin, (size_t)N * way * 2 * P * 4)); CK(hipMalloc(&labels, N * way * 8));
@@ -23,7 +24,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(d_st, 0, 64 * 8));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        int rc = denet_classify_fwd(Fq, DENET_F32, Wn, labels, N, way, K, C, P, 1, logits, bin, nullptr);
+        int rc = denet_classify_fwd(Fq, dt, Wn, labels, N, way, K, C, P, 1, logits, bin, nullptr);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -185,7 +185,7 @@ def test_c5_at_the_benchmarked_batch(dev):
     assert s.N == 8 and s.feat_dtype == "bf16"
     pl = _plan(s)
     assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 1
-    assert pl["classify_layout"] == _lib.CLS_WAVE4
+    assert pl["classify_layout"] == _lib.CLS_WAVE4_BF16
     assert pl["loss_chain_cell"] == 9
     assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 15 and pl["bwd_dfq_nt"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 0 and pl["dfs_chunked"] == 1

@@ -290,3 +290,49 @@ def test_chunked_dfs_writer_equals_the_row_writer(dev, dtype, B, C, h, w):
     assert torch.equal(a, b)
     ref = (coef.unsqueeze(2) * mask.unsqueeze(1)).reshape(B, C, h, w).to(dtype)
     assert torch.equal(b, ref)
+
+
+@pytest.mark.parametrize("N,way,K,C,h,w,base", [
+    (2, 2, 81, 256, 9, 9, True),       # odd P: the last position rides in the high half of its dword
+    (3, 1, 33, 64, 8, 9, True),        # two row tiles, C = 64 (4 k-steps, one request)
+    (2, 3, 64, 256, 16, 17, False),    # K a multiple of 32 (no zero rows), base = False takes row 0
+    (1, 2, 96, 64, 1, 2, True),        # the smallest P the kernel takes; K = the most its LDS planes hold
+    (5, 2, 81, 256, 27, 31, True),     # several blocks per episode, a partly idle last block
+])
+def test_bf16_classifier_on_the_bf16_matrix_pipe(N, way, K, C, h, w, base, dev):
+    """bf16 features with 32 < K <= 96 run classify_fwd_wide4_bf16_kernel: the fp32 class weights enter the
+    bf16 MFMA as three bf16 planes whose sum is the fp32 value exactly, so every product is exact and the result
+    differs from a float64 product only by fp32 accumulation (model/common.py:390-394).  Binary logits
+    (utils/operations.py:313-338) are selections of the kernel's own logits: bit-exact against them.  Labels
+    include a duplicate and one outside [0, K) (ch1 = 0, as the oracle)."""
+    from denet_amd import _lib, ops
+    from oracle import denet_oracle as O
+    pl = _lib.head_step_plan(N, way, 1, K, C, h, w, 4 * h, 4 * w, _lib.BF16)
+    assert pl["classify_layout"] == _lib.CLS_WAVE4_BF16
+    g = torch.Generator().manual_seed(1000 * K + h * w)
+    Fq = torch.randn(N, C, h, w, generator=g).bfloat16()
+    # weights with full 24-bit significands and a spread of magnitudes (the low plane must matter)
+    Wn = (torch.randn(N, K, C, generator=g) * torch.logspace(-3, 1, C)).contiguous()
+    lab = torch.randint(0, K, (N, way), generator=g)
+    if way > 1:
+        lab[0, 1] = lab[0, 0]
+    logits, binl = ops.classify(Fq.to(dev), Wn.to(dev), lab.to(dev), way, base=base)
+    ref = O.classify(Fq.double(), Wn.double())
+    assert rel_err(logits.cpu(), ref) < 2e-6
+    # element-wise: each logit within fp32 accumulation error of ITS OWN magnitude scale sum |w x|
+    mag = O.classify(Fq.double().abs(), Wn.double().abs())
+    assert float(((logits.cpu().double() - ref).abs() / mag).max()) < 1e-6
+    lg = logits.cpu()
+    for n in range(N):
+        for jw in range(way):
+            want = O.binary_logits(lg[n:n + 1], lab[n:n + 1, jw], base=base)
+            assert torch.equal(binl.cpu()[n * way + jw], want[0]), (n, jw)
+    # a label outside [0, K): ch1 = 0 and ch0 = the max over all rows (base) -- the stand-alone kernel's convention
+    lab2 = lab.clone()
+    lab2[0, 0] = K + 3
+    _, b2 = ops.classify(Fq.to(dev), Wn.to(dev), lab2.to(dev), way, base=base)
+    b_ref = ops.binary_logits(logits, lab2.to(dev), way, base=base)
+    assert torch.equal(b2, b_ref)
+    # the shared-weight entry point (mode='deploy', model/common.py:369-372) takes the same kernel
+    sh = ops.classify_shared(Fq.to(dev), Wn[0].to(dev))
+    assert rel_err(sh.cpu(), O.classify(Fq.double(), Wn[:1].double().expand(N, K, C))) < 2e-6
