@@ -27,11 +27,12 @@
 #include "dev_classify_fwd.hpp"
 
 // Epilogue of the wave-per-tile kernels: logits from the accumulators (C/D layout of the 32x32 MFMAs: column =
-// lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), then the binary logits.
-template <int RT>
-__device__ __forceinline__ void wide4_epilogue(f32x16 (&acc)[RT][2], const int64_t* __restrict__ labels, int way, int K,
-                                               int P, int base, float* __restrict__ logits, float* __restrict__ bin,
-                                               int n, int pa, int j, int hh) {
+// lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), then the binary logits.  A wave holds NTL column tiles;
+// column j of tile t is position pa + t (NTL = 2: pa = p0 + 2 j, the two tiles interleave; NTL = 1: pa = p0 + j).
+template <int RT, int NTL>
+__device__ __forceinline__ void wave_tile_epilogue(f32x16 (&acc)[RT][NTL], const int64_t* __restrict__ labels, int way,
+                                                   int K, int P, int base, float* __restrict__ logits,
+                                                   float* __restrict__ bin, int n, int pa, int hh) {
     // ---- logits: straight from the accumulators ----
     float* lg = logits + (int64_t)n * K * P;
 #pragma unroll
@@ -41,8 +42,12 @@ __device__ __forceinline__ void wide4_epilogue(f32x16 (&acc)[RT][2], const int64
             const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
             if (row < K) {
                 float* dst = lg + (int64_t)row * P + pa;
-                if (pa + 1 < P) *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{acc[rt][0][e], acc[rt][1][e]};
-                else if (pa < P) dst[0] = acc[rt][0][e];
+                if constexpr (NTL == 2) {
+                    if (pa + 1 < P) *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{acc[rt][0][e], acc[rt][1][e]};
+                    else if (pa < P) dst[0] = acc[rt][0][e];
+                } else {
+                    if (pa < P) dst[0] = acc[rt][0][e];
+                }
             }
         }
     if (bin == nullptr) return;
@@ -51,21 +56,23 @@ __device__ __forceinline__ void wide4_epilogue(f32x16 (&acc)[RT][2], const int64
     // per lane and position: the largest and the second largest entry over this lane's rows (ties count: two
     // equal maxima give m2 == m1), then merged across the two lane halves.  max over k != lab is then
     // m2 if the label row holds the maximum (fg == m1), else m1 -- no row index needed.
-    float m1[2] = {-INFINITY, -INFINITY}, m2[2] = {-INFINITY, -INFINITY};
+    float m1[NTL], m2[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) { m1[t] = -INFINITY; m2[t] = -INFINITY; }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NTL; ++t) {
                 const float v = row < K ? acc[rt][t][e] : -INFINITY;
                 m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);       // second largest of {m1 >= m2, v}
                 m1[t] = fmaxf(m1[t], v);
             }
         }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NTL; ++t) {
         const float o1 = __shfl_xor(m1[t], 32, 64), o2 = __shfl_xor(m2[t], 32, 64);
         const float hi = fmaxf(m1[t], o1), lo = fminf(m1[t], o1);
         m2[t] = fmaxf(lo, fmaxf(m2[t], o2));
@@ -76,35 +83,47 @@ __device__ __forceinline__ void wide4_epilogue(f32x16 (&acc)[RT][2], const int64
         const bool labok = lab64 >= 0 && lab64 < K;
         const int lab = labok ? (int)lab64 : 0;
         // the accumulator that holds row `sel`: (rt, e) are wave-uniform, the lane half is (row >> 2) & 1
-        auto pick = [&](int sel, float (&out)[2]) {
+        auto pick = [&](int sel, float (&out)[NTL]) {
             const int r = sel & 31, idx = (sel >> 5) * 16 + (r & 3) + 4 * (r >> 3), half = (r >> 2) & 1;
-            float v0 = 0.f, v1 = 0.f;
+            float v[NTL];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) v[t] = 0.f;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (idx == rt * 16 + e) { v0 = acc[rt][0][e]; v1 = acc[rt][1][e]; }     // uniform branch
-            const float w0 = __shfl_xor(v0, 32, 64), w1 = __shfl_xor(v1, 32, 64);
-            out[0] = hh == half ? v0 : w0;
-            out[1] = hh == half ? v1 : w1;
+                    if (idx == rt * 16 + e) {                                               // uniform branch
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t) v[t] = acc[rt][t][e];
+                    }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const float o = __shfl_xor(v[t], 32, 64);
+                out[t] = hh == half ? v[t] : o;
+            }
         };
-        float fg[2], outb[2];
+        float fg[NTL], outb[NTL];
         pick(lab, fg);
         if (base) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) outb[t] = (labok && fg[t] == m1[t]) ? m2[t] : m1[t];
+            for (int t = 0; t < NTL; ++t) outb[t] = (labok && fg[t] == m1[t]) ? m2[t] : m1[t];
         } else {
             pick(0, outb);
         }
         if (hh == 0) {
             float* dst = bin + ((int64_t)(n * way + jw) * 2) * P + pa;
-            const float f0 = labok ? fg[0] : 0.f, f1 = labok ? fg[1] : 0.f;
-            if (pa + 1 < P) {
-                *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{outb[0], outb[1]};
-                *reinterpret_cast<f32x2_u*>(dst + P) = f32x2_u{f0, f1};
+            if constexpr (NTL == 2) {
+                const float f0 = labok ? fg[0] : 0.f, f1 = labok ? fg[1] : 0.f;
+                if (pa + 1 < P) {
+                    *reinterpret_cast<f32x2_u*>(dst) = f32x2_u{outb[0], outb[1]};
+                    *reinterpret_cast<f32x2_u*>(dst + P) = f32x2_u{f0, f1};
+                } else if (pa < P) {
+                    dst[0] = outb[0];
+                    dst[P] = f0;
+                }
             } else if (pa < P) {
                 dst[0] = outb[0];
-                dst[P] = f0;
+                dst[P] = labok ? fg[0] : 0.f;
             }
         }
     }
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __rest
     }
 
     STAMP(2);
-    wide4_epilogue<RT>(acc, labels, way, K, P, base, logits, bin, n, pa, j, hh);
+    wave_tile_epilogue<RT, 2>(acc, labels, way, K, P, base, logits, bin, n, pa, hh);
     STAMP(4);
 }
 
@@ -243,6 +262,41 @@ __device__ __forceinline__ void split_bf16x3(float w, unsigned& h, unsigned& m, 
     m = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(m);              // <= 8 significant bits
     l = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// After stage_wn + a barrier (256 threads): BUILD writes this block's share of Wn[n] for the backward pass, then
+// the fp32 image [32 RT][C + 1] becomes the three bf16 planes [3][32 RT][C + 8], in place through registers.
+// Ends with a barrier.
+template <int RT, bool BUILD, int CJ>
+__device__ __forceinline__ void wn_image_to_planes(float* sm, const WnBuild& wb, int n, int K) {
+    constexpr int C = 64 * CJ, NR = 32 * RT, LDD = (C + 8) / 2, ldw = C + 1;
+    const int tid = threadIdx.x;
+    if constexpr (BUILD) {
+        float* dst = wb.Wn_out + (int64_t)n * K * C;
+        for (int k = blockIdx.x; k < K; k += gridDim.x)
+            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
+    }
+    constexpr int PER = NR * (C / 2) / 256;        // channel pairs per thread (48 at RT = 3, C = 256)
+    float v0[PER], v1[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
+        v0[q] = sm[row * ldw + 2 * cp];
+        v1[q] = sm[row * ldw + 2 * cp + 1];
+    }
+    __syncthreads();
+    unsigned* pl = reinterpret_cast<unsigned*>(sm);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_bf16x3(v0[q], h0, m0, l0);
+        split_bf16x3(v1[q], h1, m1, l1);
+        pl[(0 * NR + row) * LDD + cp] = (h0 >> 16) | h1;
+        pl[(1 * NR + row) * LDD + cp] = (m0 >> 16) | m1;
+        pl[(2 * NR + row) * LDD + cp] = (l0 >> 16) | l1;
+    }
+    __syncthreads();
 }
 
 #define CLB_LDS(RT, C) ((size_t)3 * 32 * (RT) * ((C) + 8) * 2)
@@ -300,35 +354,7 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
 
     __syncthreads();
     STAMP(3);
-    if constexpr (BUILD) {
-        float* dst = wb.Wn_out + (int64_t)n * K * C;
-        for (int k = blockIdx.x; k < K; k += gridDim.x)
-            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
-    }
-    // ---- fp32 image [NR][C + 1] -> bf16 planes [3][NR][C + 8], in place through registers ----
-    {
-        constexpr int PER = NR * (C / 2) / 256;    // channel pairs per thread (48 at RT = 3, C = 256)
-        float v0[PER], v1[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
-            v0[q] = sm[row * ldw + 2 * cp];
-            v1[q] = sm[row * ldw + 2 * cp + 1];
-        }
-        __syncthreads();
-        unsigned* pl = reinterpret_cast<unsigned*>(sm);
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
-            unsigned h0, m0, l0, h1, m1, l1;
-            split_bf16x3(v0[q], h0, m0, l0);
-            split_bf16x3(v1[q], h1, m1, l1);
-            pl[(0 * NR + row) * LDD + cp] = (h0 >> 16) | h1;
-            pl[(1 * NR + row) * LDD + cp] = (m0 >> 16) | m1;
-            pl[(2 * NR + row) * LDD + cp] = (l0 >> 16) | l1;
-        }
-        __syncthreads();
-    }
+    wn_image_to_planes<RT, BUILD, CJ>(sm, wb, n, K);
     request(KH, KS);
     if (!active) return;                           // (no barrier below this line)
     STAMP(4);
@@ -376,8 +402,130 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
         __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(5);
-    wide4_epilogue<RT>(acc, labels, way, K, P, base, logits, bin, n, pa, j, hh);
+    wave_tile_epilogue<RT, 2>(acc, labels, way, K, P, base, logits, bin, n, pa, hh);
     STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
+// fp32 features, 32 < K <= 96, on the bf16 matrix pipe: BOTH operands as bf16 planes.  Wn[n] = Wh + Wm + Wl as
+// above; every Fq element is split the same way in registers as it arrives (5 VALU ops: and / sub / and / sub /
+// and), x = xh + xm + xl exactly.  Of the nine partial products the six of order <= 2 are taken,
+//   Wh xh + Wh xm + Wm xh + Wh xl + Wl xh + Wm xm,
+// each exact in the fp32 accumulator; the three dropped (Wm xl, Wl xm, Wl xl) are each below 2^-24 |w x|, the
+// size of ONE fp32 rounding of the product -- the error class of the fmaf chain this replaces (and of the
+// reference's own fp32 GEMM).  Six bf16 MFMAs of 16 channels (6 x 32 cycles) stand where the fp32 instruction
+// needs 8 MFMAs of 2 channels (8 x 64): 2.7x less matrix time, the splits ride on the VALU beside them.
+// Work layout: a block owns a contiguous range of 32-POSITION half tiles of one episode (N x groups <= 256
+// blocks, at least four half tiles per block where there are that many), its four waves take them round-robin;
+// a wave holds all K rows of its half tile, so logits and binary logits leave straight from the accumulators.
+// The lane's B operand is one dword per channel (lane = position j, channels 8 hh + i of each k-step), requested
+// in two halves as in the bf16 kernel; the next half tile's first half goes out before the epilogue's stores.
+// ---------------------------------------------------------------------------
+template <int RT, bool BUILD, int CJ>
+__global__ __launch_bounds__(256) void classify_fwd_split_f32_kernel(const float* __restrict__ Fq,
+                                                                   const float* __restrict__ Wn, int64_t wn_stride,
+                                                                   const int64_t* __restrict__ labels, int way, int K,
+                                                                   int P, int base, float* __restrict__ logits,
+                                                                   float* __restrict__ bin, WnBuild wb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = 64 * CJ, NR = 32 * RT;
+    constexpr int KS = C / 16;                     // k-steps of 16 channels
+    constexpr int LDD = (C + 8) / 2;               // dwords per plane row
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ldw = C + 1;
+    const int nht = (P + 31) >> 5;                 // half tiles of the episode
+    const int h0 = (int)((int64_t)blockIdx.x * nht / gridDim.x), h1 = (int)((int64_t)(blockIdx.x + 1) * nht / gridDim.x);
+    const float* fq = Fq + (int64_t)n * C * P;
+
+    STAMP(0);
+    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : 24;
+    stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
+    for (int i = K * ldw + tid; i < NR * ldw; i += 256) sm[i] = 0.f;           // zero rows K .. 32 RT - 1
+    STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    float x[KS][8];
+    // (uniform base + one running 32-bit lane offset: 128 precomputed row offsets would live in spilled SGPRs)
+    auto request = [&](int ht, int q0, int q1) {   // unconditional; columns past P read the last position
+        unsigned off = (unsigned)(16 * q0 + 8 * hh) * (unsigned)P + (unsigned)min(ht * 32 + j, P - 1);   // C * P < 2^31
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                x[q][i] = fq[off];
+                off += (unsigned)P;
+            }
+            off += 8u * (unsigned)P;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int KH = KS > 4 ? KS / 2 : KS;
+    int ht = h0 + wave;                            // an idle wave (ht >= h1) requests a valid tile and drops it
+    request(min(ht, nht - 1), 0, KH);
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+    wn_image_to_planes<RT, BUILD, CJ>(sm, wb, n, K);
+    request(min(ht, nht - 1), KH, KS);             // (no barrier below this line)
+    STAMP(4);
+
+    const unsigned* pla = reinterpret_cast<const unsigned*>(sm) + j * LDD + 4 * hh;
+#pragma unroll 1
+    for (; ht < h1; ht += 4) {
+        f32x16 acc[RT][1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][0][e] = 0.f;
+        // B planes of k-step q + 1 are formed (52 VALU ops) in the shadow of the MFMAs of k-step q: the wave
+        // issues in order and an MFMA holds the issue port only until the pipe takes it, so VALU work placed
+        // BETWEEN MFMAs is free while VALU work in front of them is not (7.3 -> us per half tile measured)
+        u32x4 bq[2][3];
+        auto planes = [&](int q, u32x4 (&b)[3]) {
+            unsigned xh[8], xm[8], xl[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_bf16x3(x[q][i], xh[i], xm[i], xl[i]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {          // channel 2m in the low half, 2m + 1 in the high half
+                b[0][m] = __builtin_amdgcn_perm(xh[2 * m + 1], xh[2 * m], 0x07060302u);
+                b[1][m] = __builtin_amdgcn_perm(xm[2 * m + 1], xm[2 * m], 0x07060302u);
+                b[2][m] = __builtin_amdgcn_perm(xl[2 * m + 1], xl[2 * m], 0x07060302u);
+            }
+        };
+        planes(0, bq[0]);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            u32x4 af[3][RT];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    af[s][rt] = *reinterpret_cast<const u32x4*>(pla + (s * NR + 32 * rt) * LDD + 8 * q);
+            if (q + 1 < KS) planes(q + 1, bq[(q + 1) & 1]);
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, bq[q & 1][0]), Bm = __builtin_bit_cast(bf16x8, bq[q & 1][1]),
+                         Bl = __builtin_bit_cast(bf16x8, bq[q & 1][2]);
+            // smallest terms first; the row tiles interleave so that no MFMA waits on the one before it
+#define CLS_TERM(S, B)                                                                                          \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(     \
+        __builtin_bit_cast(bf16x8, af[S][rt]), B, acc[rt][0], 0, 0, 0);
+            CLS_TERM(1, Bm) CLS_TERM(2, Bh) CLS_TERM(0, Bl) CLS_TERM(1, Bh) CLS_TERM(0, Bm) CLS_TERM(0, Bh)
+#undef CLS_TERM
+            // issue order of this k-step: the A reads, then one MFMA / three VALU ops, 6 RT times
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * RT, 0);          // DS reads
+#pragma unroll
+            for (int g = 0; g < 6 * RT; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);           // VALU
+            }
+        }
+        STAMP(5);
+        const int nxt = ht + 4;
+        if (nxt < h1) request(nxt, 0, KH);         // uniform; x is dead here
+        wave_tile_epilogue<RT, 1>(acc, labels, way, K, P, base, logits, bin, n, ht * 32 + j, hh);
+        if (nxt < h1) request(nxt, KH, KS);
+        STAMP(6);
+    }
 }
 
 // K > 32: the MFMA work of an episode is spread over as many CUs as there are (one block per CU: Wn[n] takes
@@ -630,7 +778,8 @@ static int set_lds(KernelT kern, size_t lds) {
 
 // Forward layout for a shape (also reported by denet_head_step_plan): DENET_CLS_TILE8 = eight waves per
 // 64-position tile (K <= 32, few tiles), DENET_CLS_UNITS = layout (a) below, DENET_CLS_WAVE4 = layout (b),
-// DENET_CLS_WAVE4_BF16 = layout (b) on the bf16 matrix pipe (bf16 features, 32 < K <= 96).
+// DENET_CLS_WAVE4_BF16 = layout (b) on the bf16 matrix pipe (bf16 features, 32 < K <= 96), DENET_CLS_SPLIT_F32 =
+// fp32 features of the same K range on the bf16 pipe (half-tile ranges; `groups` = blocks per episode).
 // `groups` (layout (a): blocks per episode) is returned through the pointer when it is not null.
 int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, int64_t* groups_out) {
     const int RT = (int)((K + 31) / 32);
@@ -638,6 +787,16 @@ int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, i
     // bf16 features: the split-weight bf16 MFMA kernel wherever Wn[n] stays resident (its three planes fit in
     // LDS up to K = 96); its matrix work is a fifth of the fp32 instruction's, so the unit layout has nothing to win
     if (feat_dtype == DENET_BF16 && (RT == 2 || RT == 3)) return DENET_CLS_WAVE4_BF16;
+    // fp32 features, same K range: both operands as bf16 planes; a block takes a range of half tiles
+#ifndef DENET_NO_SPLIT_F32
+    if (feat_dtype == DENET_F32 && (RT == 2 || RT == 3)) {
+        const int64_t nht = (P + 31) / 32;
+        int64_t g = 256 / N < 1 ? 1 : 256 / N;
+        if (g > (nht + 3) / 4) g = (nht + 3) / 4;
+        if (groups_out) *groups_out = g;
+        return DENET_CLS_SPLIT_F32;
+    }
+#endif
     // K <= 32 with many tiles: layout (b) (a wave per tile, Wn staged once per four tiles) instead of the
     // latency-oriented eight-waves-per-tile kernel
     // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
@@ -683,6 +842,27 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
             if (RT == 2) { if (C == 64) CL_WIDE4B(2, 1) else CL_WIDE4B(2, 4) }
             else { if (C == 64) CL_WIDE4B(3, 1) else CL_WIDE4B(3, 4) }
 #undef CL_WIDE4B
+            DENET_CHECK_LAUNCH();
+            return DENET_OK;
+        } else {
+            return DENET_E_UNSUPPORTED;
+        }
+    }
+    if (layout == DENET_CLS_SPLIT_F32) {
+        if constexpr (std::is_same<T, float>::value) {
+            const size_t ldsb = CLB_LDS(RT, C);
+            if (ldsb > 160 * 1024) return DENET_E_UNSUPPORTED;
+            dim3 grids((unsigned)groups, (unsigned)N), blocks(256);
+#define CL_SPLIT(R, J)                                                                                        \
+    {                                                                                                         \
+        int rc = set_lds(classify_fwd_split_f32_kernel<R, BUILD, J>, ldsb);                                   \
+        if (rc) return rc;                                                                                    \
+        hipLaunchKernelGGL((classify_fwd_split_f32_kernel<R, BUILD, J>), grids, blocks, ldsb, st, Fq, Wn, wn_stride, \
+                           labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
+    }
+            if (RT == 2) { if (C == 64) CL_SPLIT(2, 1) else CL_SPLIT(2, 4) }
+            else { if (C == 64) CL_SPLIT(3, 1) else CL_SPLIT(3, 4) }
+#undef CL_SPLIT
             DENET_CHECK_LAUNCH();
             return DENET_OK;
         } else {

@@ -299,18 +299,23 @@ def test_chunked_dfs_writer_equals_the_row_writer(dev, dtype, B, C, h, w):
     (1, 2, 96, 64, 1, 2, True),        # the smallest P the kernel takes; K = the most its LDS planes hold
     (5, 2, 81, 256, 27, 31, True),     # several blocks per episode, a partly idle last block
 ])
-def test_bf16_classifier_on_the_bf16_matrix_pipe(N, way, K, C, h, w, base, dev):
-    """bf16 features with 32 < K <= 96 run classify_fwd_wide4_bf16_kernel: the fp32 class weights enter the
-    bf16 MFMA as three bf16 planes whose sum is the fp32 value exactly, so every product is exact and the result
-    differs from a float64 product only by fp32 accumulation (model/common.py:390-394).  Binary logits
+@pytest.mark.parametrize("feat", ["bf16", "f32"])
+def test_classifier_on_the_bf16_matrix_pipe(N, way, K, C, h, w, base, feat, dev):
+    """32 < K <= 96 runs on the bf16 matrix pipe.  bf16 features (classify_fwd_wide4_bf16_kernel): the fp32 class
+    weights enter the MFMA as three bf16 planes whose sum is the fp32 value exactly, so every product is exact and
+    the result differs from a float64 product only by fp32 accumulation (model/common.py:390-394).  fp32 features
+    (classify_fwd_split_f32_kernel): the features are split the same way and six of the nine partial products are
+    taken; the dropped ones are below 2^-24 of a product each, so the same bounds hold.  Binary logits
     (utils/operations.py:313-338) are selections of the kernel's own logits: bit-exact against them.  Labels
     include a duplicate and one outside [0, K) (ch1 = 0, as the oracle)."""
     from denet_amd import _lib, ops
     from oracle import denet_oracle as O
-    pl = _lib.head_step_plan(N, way, 1, K, C, h, w, 4 * h, 4 * w, _lib.BF16)
-    assert pl["classify_layout"] == _lib.CLS_WAVE4_BF16
+    pl = _lib.head_step_plan(N, way, 1, K, C, h, w, 4 * h, 4 * w, _lib.BF16 if feat == "bf16" else _lib.F32)
+    assert pl["classify_layout"] == (_lib.CLS_WAVE4_BF16 if feat == "bf16" else _lib.CLS_SPLIT_F32)
     g = torch.Generator().manual_seed(1000 * K + h * w)
-    Fq = torch.randn(N, C, h, w, generator=g).bfloat16()
+    Fq = torch.randn(N, C, h, w, generator=g)
+    # (fp32: a spread of magnitudes over the channels too, so the low planes of BOTH operands matter)
+    Fq = Fq.bfloat16() if feat == "bf16" else Fq * torch.logspace(1, -3, C).reshape(1, C, 1, 1)
     # weights with full 24-bit significands and a spread of magnitudes (the low plane must matter)
     Wn = (torch.randn(N, K, C, generator=g) * torch.logspace(-3, 1, C)).contiguous()
     lab = torch.randint(0, K, (N, way), generator=g)
