@@ -88,7 +88,7 @@ class StepPlan(ctypes.Structure):
         "dfs_nt", "dfs_flat_writer", "dfs_chunked")] + [("reserved", ctypes.c_int32 * 2)]
 
 
-CLS_TILE8, CLS_UNITS, CLS_WAVE4, CLS_WAVE4_BF16, CLS_SPLIT_F32 = 0, 1, 2, 3, 4
+CLS_TILE8, CLS_UNITS, CLS_WAVE4, CLS_WAVE4_BF16 = 0, 1, 2, 3
 
 
 def head_step_plan(N, way, shot, K, C, h, w, H, W, feat_dtype=None):

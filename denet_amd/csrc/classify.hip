@@ -406,128 +406,6 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
     STAMP(6);
 }
 
-// ---------------------------------------------------------------------------
-// fp32 features, 32 < K <= 96, on the bf16 matrix pipe: BOTH operands as bf16 planes.  Wn[n] = Wh + Wm + Wl as
-// above; every Fq element is split the same way in registers as it arrives (5 VALU ops: and / sub / and / sub /
-// and), x = xh + xm + xl exactly.  Of the nine partial products the six of order <= 2 are taken,
-//   Wh xh + Wh xm + Wm xh + Wh xl + Wl xh + Wm xm,
-// each exact in the fp32 accumulator; the three dropped (Wm xl, Wl xm, Wl xl) are each below 2^-24 |w x|, the
-// size of ONE fp32 rounding of the product -- the error class of the fmaf chain this replaces (and of the
-// reference's own fp32 GEMM).  Six bf16 MFMAs of 16 channels (6 x 32 cycles) stand where the fp32 instruction
-// needs 8 MFMAs of 2 channels (8 x 64): 2.7x less matrix time, the splits ride on the VALU beside them.
-// Work layout: a block owns a contiguous range of 32-POSITION half tiles of one episode (N x groups <= 256
-// blocks, at least four half tiles per block where there are that many), its four waves take them round-robin;
-// a wave holds all K rows of its half tile, so logits and binary logits leave straight from the accumulators.
-// The lane's B operand is one dword per channel (lane = position j, channels 8 hh + i of each k-step), requested
-// in two halves as in the bf16 kernel; the next half tile's first half goes out before the epilogue's stores.
-// ---------------------------------------------------------------------------
-template <int RT, bool BUILD, int CJ>
-__global__ __launch_bounds__(256) void classify_fwd_split_f32_kernel(const float* __restrict__ Fq,
-                                                                   const float* __restrict__ Wn, int64_t wn_stride,
-                                                                   const int64_t* __restrict__ labels, int way, int K,
-                                                                   int P, int base, float* __restrict__ logits,
-                                                                   float* __restrict__ bin, WnBuild wb) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int C = 64 * CJ, NR = 32 * RT;
-    constexpr int KS = C / 16;                     // k-steps of 16 channels
-    constexpr int LDD = (C + 8) / 2;               // dwords per plane row
-    const int n = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int ldw = C + 1;
-    const int nht = (P + 31) >> 5;                 // half tiles of the episode
-    const int h0 = (int)((int64_t)blockIdx.x * nht / gridDim.x), h1 = (int)((int64_t)(blockIdx.x + 1) * nht / gridDim.x);
-    const float* fq = Fq + (int64_t)n * C * P;
-
-    STAMP(0);
-    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : 24;
-    stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
-    for (int i = K * ldw + tid; i < NR * ldw; i += 256) sm[i] = 0.f;           // zero rows K .. 32 RT - 1
-    STAMP(1);
-    __builtin_amdgcn_sched_barrier(0);
-    float x[KS][8];
-    // (uniform base + one running 32-bit lane offset: 128 precomputed row offsets would live in spilled SGPRs)
-    auto request = [&](int ht, int q0, int q1) {   // unconditional; columns past P read the last position
-        unsigned off = (unsigned)(16 * q0 + 8 * hh) * (unsigned)P + (unsigned)min(ht * 32 + j, P - 1);   // C * P < 2^31
-#pragma unroll
-        for (int q = q0; q < q1; ++q) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                x[q][i] = fq[off];
-                off += (unsigned)P;
-            }
-            off += 8u * (unsigned)P;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    constexpr int KH = KS > 4 ? KS / 2 : KS;
-    int ht = h0 + wave;                            // an idle wave (ht >= h1) requests a valid tile and drops it
-    request(min(ht, nht - 1), 0, KH);
-    STAMP(2);
-    __syncthreads();
-    STAMP(3);
-    wn_image_to_planes<RT, BUILD, CJ>(sm, wb, n, K);
-    request(min(ht, nht - 1), KH, KS);             // (no barrier below this line)
-    STAMP(4);
-
-    const unsigned* pla = reinterpret_cast<const unsigned*>(sm) + j * LDD + 4 * hh;
-#pragma unroll 1
-    for (; ht < h1; ht += 4) {
-        f32x16 acc[RT][1];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][0][e] = 0.f;
-        // B planes of k-step q + 1 are formed (52 VALU ops) in the shadow of the MFMAs of k-step q: the wave
-        // issues in order and an MFMA holds the issue port only until the pipe takes it, so VALU work placed
-        // BETWEEN MFMAs is free while VALU work in front of them is not (7.3 -> us per half tile measured)
-        u32x4 bq[2][3];
-        auto planes = [&](int q, u32x4 (&b)[3]) {
-            unsigned xh[8], xm[8], xl[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) split_bf16x3(x[q][i], xh[i], xm[i], xl[i]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {          // channel 2m in the low half, 2m + 1 in the high half
-                b[0][m] = __builtin_amdgcn_perm(xh[2 * m + 1], xh[2 * m], 0x07060302u);
-                b[1][m] = __builtin_amdgcn_perm(xm[2 * m + 1], xm[2 * m], 0x07060302u);
-                b[2][m] = __builtin_amdgcn_perm(xl[2 * m + 1], xl[2 * m], 0x07060302u);
-            }
-        };
-        planes(0, bq[0]);
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-            u32x4 af[3][RT];
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    af[s][rt] = *reinterpret_cast<const u32x4*>(pla + (s * NR + 32 * rt) * LDD + 8 * q);
-            if (q + 1 < KS) planes(q + 1, bq[(q + 1) & 1]);
-            const bf16x8 Bh = __builtin_bit_cast(bf16x8, bq[q & 1][0]), Bm = __builtin_bit_cast(bf16x8, bq[q & 1][1]),
-                         Bl = __builtin_bit_cast(bf16x8, bq[q & 1][2]);
-            // smallest terms first; the row tiles interleave so that no MFMA waits on the one before it
-#define CLS_TERM(S, B)                                                                                          \
-    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(     \
-        __builtin_bit_cast(bf16x8, af[S][rt]), B, acc[rt][0], 0, 0, 0);
-            CLS_TERM(1, Bm) CLS_TERM(2, Bh) CLS_TERM(0, Bl) CLS_TERM(1, Bh) CLS_TERM(0, Bm) CLS_TERM(0, Bh)
-#undef CLS_TERM
-            // issue order of this k-step: the A reads, then one MFMA / three VALU ops, 6 RT times
-            __builtin_amdgcn_sched_group_barrier(0x100, 3 * RT, 0);          // DS reads
-#pragma unroll
-            for (int g = 0; g < 6 * RT; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);           // VALU
-            }
-        }
-        STAMP(5);
-        const int nxt = ht + 4;
-        if (nxt < h1) request(nxt, 0, KH);         // uniform; x is dead here
-        wave_tile_epilogue<RT, 1>(acc, labels, way, K, P, base, logits, bin, n, ht * 32 + j, hh);
-        if (nxt < h1) request(nxt, KH, KS);
-        STAMP(6);
-    }
-}
-
 // K > 32: the MFMA work of an episode is spread over as many CUs as there are (one block per CU: Wn[n] takes
 // 32 RT rows of LDS) and, inside a block, evenly over the four SIMDs.  A block owns a contiguous range of
 // 32-POSITION half tiles of one episode, the ranges cut so that N x groups ~ 256 blocks (C3: 12 blocks of 4-5 half
@@ -778,8 +656,7 @@ static int set_lds(KernelT kern, size_t lds) {
 
 // Forward layout for a shape (also reported by denet_head_step_plan): DENET_CLS_TILE8 = eight waves per
 // 64-position tile (K <= 32, few tiles), DENET_CLS_UNITS = layout (a) below, DENET_CLS_WAVE4 = layout (b),
-// DENET_CLS_WAVE4_BF16 = layout (b) on the bf16 matrix pipe (bf16 features, 32 < K <= 96), DENET_CLS_SPLIT_F32 =
-// fp32 features of the same K range on the bf16 pipe (half-tile ranges; `groups` = blocks per episode).
+// DENET_CLS_WAVE4_BF16 = layout (b) on the bf16 matrix pipe (bf16 features, 32 < K <= 96).
 // `groups` (layout (a): blocks per episode) is returned through the pointer when it is not null.
 int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, int64_t* groups_out) {
     const int RT = (int)((K + 31) / 32);
@@ -787,16 +664,6 @@ int denet_classify_fwd_layout(int feat_dtype, int64_t N, int64_t K, int64_t P, i
     // bf16 features: the split-weight bf16 MFMA kernel wherever Wn[n] stays resident (its three planes fit in
     // LDS up to K = 96); its matrix work is a fifth of the fp32 instruction's, so the unit layout has nothing to win
     if (feat_dtype == DENET_BF16 && (RT == 2 || RT == 3)) return DENET_CLS_WAVE4_BF16;
-    // fp32 features, same K range: both operands as bf16 planes; a block takes a range of half tiles
-#ifndef DENET_NO_SPLIT_F32
-    if (feat_dtype == DENET_F32 && (RT == 2 || RT == 3)) {
-        const int64_t nht = (P + 31) / 32;
-        int64_t g = 256 / N < 1 ? 1 : 256 / N;
-        if (g > (nht + 3) / 4) g = (nht + 3) / 4;
-        if (groups_out) *groups_out = g;
-        return DENET_CLS_SPLIT_F32;
-    }
-#endif
     // K <= 32 with many tiles: layout (b) (a wave per tile, Wn staged once per four tiles) instead of the
     // latency-oriented eight-waves-per-tile kernel
     // (C2: 12.9 vs 18.2 us at 8 episodes = 216 tiles, 23.9 vs 19.9 at 16, 144 vs 72 at 128)
@@ -842,27 +709,6 @@ static int launch_classify_fwd(const T* Fq, const float* Wn, int64_t wn_stride, 
             if (RT == 2) { if (C == 64) CL_WIDE4B(2, 1) else CL_WIDE4B(2, 4) }
             else { if (C == 64) CL_WIDE4B(3, 1) else CL_WIDE4B(3, 4) }
 #undef CL_WIDE4B
-            DENET_CHECK_LAUNCH();
-            return DENET_OK;
-        } else {
-            return DENET_E_UNSUPPORTED;
-        }
-    }
-    if (layout == DENET_CLS_SPLIT_F32) {
-        if constexpr (std::is_same<T, float>::value) {
-            const size_t ldsb = CLB_LDS(RT, C);
-            if (ldsb > 160 * 1024) return DENET_E_UNSUPPORTED;
-            dim3 grids((unsigned)groups, (unsigned)N), blocks(256);
-#define CL_SPLIT(R, J)                                                                                        \
-    {                                                                                                         \
-        int rc = set_lds(classify_fwd_split_f32_kernel<R, BUILD, J>, ldsb);                                   \
-        if (rc) return rc;                                                                                    \
-        hipLaunchKernelGGL((classify_fwd_split_f32_kernel<R, BUILD, J>), grids, blocks, ldsb, st, Fq, Wn, wn_stride, \
-                           labels, (int)way, (int)K, (int)P, base, logits, bin, wb);                          \
-    }
-            if (RT == 2) { if (C == 64) CL_SPLIT(2, 1) else CL_SPLIT(2, 4) }
-            else { if (C == 64) CL_SPLIT(3, 1) else CL_SPLIT(3, 4) }
-#undef CL_SPLIT
             DENET_CHECK_LAUNCH();
             return DENET_OK;
         } else {

@@ -240,8 +240,7 @@ extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_
     p.pool_nt_loads = pl.nt_loads;
     int64_t groups = 0;
     p.classify_layout = denet_classify_fwd_layout(feat_dtype, N, K, P, &groups);
-    p.classify_groups =
-        (p.classify_layout == DENET_CLS_UNITS || p.classify_layout == DENET_CLS_SPLIT_F32) ? (int32_t)groups : 0;
+    p.classify_groups = p.classify_layout == DENET_CLS_UNITS ? (int32_t)groups : 0;
     LossPlan lp;
     if (!denet_loss_plan(K, h, w, H, W, true, &lp)) return DENET_E_UNSUPPORTED;
     p.loss_chain_cell = lp.chain_cell;

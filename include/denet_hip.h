@@ -289,14 +289,12 @@ int64_t denet_head_step_workspace(int64_t N, int64_t way, int64_t shot, int64_t 
 #define DENET_CLS_WAVE4   2   /* a wave per tile, four tiles per block                                 */
 #define DENET_CLS_WAVE4_BF16 3 /* bf16 features, 32 < K <= 96: the same block shape on the bf16 matrix pipe,
                                   class weights split into three bf16 planes (exact)                    */
-#define DENET_CLS_SPLIT_F32 4  /* fp32 features, 32 < K <= 96: both operands as bf16 planes, six of the nine
-                                  partial products (the dropped ones < 2^-24 of a product each)         */
 typedef struct denet_step_plan {
     int32_t pool_launches;    /* 1: mask gathered inside the pooling kernel; 2: flat mask resize first       */
     int32_t pool_long_rows;   /* rolling-loop pooling kernel (rows of more than 512 16-byte vectors)         */
     int32_t pool_nt_loads;    /* Fs read with non-temporal loads (stream > 160 MB)                           */
     int32_t classify_layout;  /* DENET_CLS_*                                                                 */
-    int32_t classify_groups;  /* DENET_CLS_UNITS / DENET_CLS_SPLIT_F32: blocks per episode, else 0           */
+    int32_t classify_groups;  /* DENET_CLS_UNITS: blocks per episode, else 0                                 */
     int32_t loss_chain_cell;  /* 8 / 9: chain kernel with that many label columns per cell; 0: exact kernel  */
     int32_t loss_chunk;       /* chain kernel: classes per table chunk                                       */
     int32_t loss_xsplit;      /* column ranges per low-res row                                               */

@@ -158,7 +158,7 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
     """C3 forward AND backward at the 20 episodes profiles/*_bench_c3.json times, against the oracle (about a
     second on the host).  The launchers pick kernel variants from the sizes alone; the plan query reports what
     this shape runs, so the test fails if a threshold moves the benchmark onto a path it does not check:
-    flat mask resize + non-temporal Fs loads (344 MB), split-operand bf16-pipe classifier with 12 blocks per episode,
+    flat mask resize + non-temporal Fs loads (344 MB), classifier layout (a) with 12 blocks per episode,
     chain loss kernel on 8-column cells, persistent backward with 6 tile groups, non-temporal dFq stores,
     the flat non-temporal fp32 dFs writer."""
     from denet_amd import _lib
@@ -167,7 +167,7 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
     assert s.N == 20
     pl = _plan(s)
     assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 0
-    assert pl["classify_layout"] == _lib.CLS_SPLIT_F32 and pl["classify_groups"] == 12
+    assert pl["classify_layout"] == _lib.CLS_UNITS and pl["classify_groups"] == 12
     assert pl["loss_chain_cell"] == 8 and 1 < (s.K + pl["loss_chunk"] - 1) // pl["loss_chunk"] <= 5
     assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 6 and pl["bwd_dfq_nt"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 1 and pl["dfs_chunked"] == 0

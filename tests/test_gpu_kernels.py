@@ -301,20 +301,19 @@ def test_chunked_dfs_writer_equals_the_row_writer(dev, dtype, B, C, h, w):
 ])
 @pytest.mark.parametrize("feat", ["bf16", "f32"])
 def test_classifier_on_the_bf16_matrix_pipe(N, way, K, C, h, w, base, feat, dev):
-    """32 < K <= 96 runs on the bf16 matrix pipe.  bf16 features (classify_fwd_wide4_bf16_kernel): the fp32 class
+    """bf16 features with 32 < K <= 96 run on the bf16 matrix pipe (classify_fwd_wide4_bf16_kernel): the fp32 class
     weights enter the MFMA as three bf16 planes whose sum is the fp32 value exactly, so every product is exact and
     the result differs from a float64 product only by fp32 accumulation (model/common.py:390-394).  fp32 features
-    (classify_fwd_split_f32_kernel): the features are split the same way and six of the nine partial products are
-    taken; the dropped ones are below 2^-24 of a product each, so the same bounds hold.  Binary logits
+    of the same shapes (the fp32-MFMA layouts) are held to the same bounds.  Binary logits
     (utils/operations.py:313-338) are selections of the kernel's own logits: bit-exact against them.  Labels
     include a duplicate and one outside [0, K) (ch1 = 0, as the oracle)."""
     from denet_amd import _lib, ops
     from oracle import denet_oracle as O
     pl = _lib.head_step_plan(N, way, 1, K, C, h, w, 4 * h, 4 * w, _lib.BF16 if feat == "bf16" else _lib.F32)
-    assert pl["classify_layout"] == (_lib.CLS_WAVE4_BF16 if feat == "bf16" else _lib.CLS_SPLIT_F32)
+    assert (pl["classify_layout"] == _lib.CLS_WAVE4_BF16) == (feat == "bf16")
     g = torch.Generator().manual_seed(1000 * K + h * w)
     Fq = torch.randn(N, C, h, w, generator=g)
-    # (fp32: a spread of magnitudes over the channels too, so the low planes of BOTH operands matter)
+    # (fp32: a spread of magnitudes over the channels too)
     Fq = Fq.bfloat16() if feat == "bf16" else Fq * torch.logspace(1, -3, C).reshape(1, C, 1, 1)
     # weights with full 24-bit significands and a spread of magnitudes (the low plane must matter)
     Wn = (torch.randn(N, K, C, generator=g) * torch.logspace(-3, 1, C)).contiguous()
