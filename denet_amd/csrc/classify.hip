@@ -242,15 +242,15 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __rest
 //   logits = sum_c (hi + mid + lo)[k][c] * Fq[c][p]          3 MFMAs of 16 channels instead of 8 of 2.
 // Matrix work per SIMD at K = 81, C = 256: 288 MFMAs x 32 cycles = 9.2 k cycles against 768 x 64 = 49 k, which
 // leaves the kernel bound by its loads -- so ALL of the wave's Fq (C/2 dwords per lane: 8 channels x 2 adjacent
-// positions per 16-channel k-step) is requested right after the Wn loads have landed in LDS and arrives under the
-// plane conversion; the MFMA loop consumes the k-steps as their loads retire.
+// positions per 16-channel k-step) is requested in two halves right after the Wn planes are written (Wn first: vmcnt
+// retires in order); the MFMA loop consumes the k-steps as their loads retire.
 //   A operand (Wn planes): lane (r = lane & 31, h = lane >> 5) holds row r, channels c0 + 8h .. 8h+7 = one
 //     ds_read_b128 of plane[s][32 rt + r]; plane rows are C + 8 bf16 (528 B: 16 lanes x 16 B cover the 64 banks).
 //   B operand (Fq): the same lane holds channels c0 + 8h + i of column r; the dword loaded for channel i carries
 //     positions pa (low half) and pa + 1 (high half) = column r of tile 0 and of tile 1, so two v_perm_b32 per
 //     channel pair build both tiles' fragments.
-// LDS: 3 x 32 RT x (C + 8) x 2 B = 152 KB at RT = 3 (the fp32 image is staged first in the same bytes and
-// converted through registers).
+// LDS: 3 x 32 RT x (C + 8) x 2 B = 152 KB at RT = 3 (the planes are written straight from the global loads,
+// stage_wn_planes: no fp32 image in between).
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -264,39 +264,123 @@ __device__ __forceinline__ void split_bf16x3(float w, unsigned& h, unsigned& m, 
     l = __float_as_uint(r2) & 0xffff0000u;
 }
 
-// After stage_wn + a barrier (256 threads): BUILD writes this block's share of Wn[n] for the backward pass, then
-// the fp32 image [32 RT][C + 1] becomes the three bf16 planes [3][32 RT][C + 8], in place through registers.
-// Ends with a barrier.
-template <int RT, bool BUILD, int CJ>
-__device__ __forceinline__ void wn_image_to_planes(float* sm, const WnBuild& wb, int n, int K) {
-    constexpr int C = 64 * CJ, NR = 32 * RT, LDD = (C + 8) / 2, ldw = C + 1;
+// Wn[n] from global memory straight into the three bf16 planes (no fp32 image, no second pass through LDS): the
+// loads, row selection and dropout of stage_wn, then split_bf16x3 on the loaded registers and 8-byte plane
+// stores.  Rows K .. 32 RT - 1 are written as zeros.  BUILD: the block also writes its share of the assembled
+// fp32 Wn[n] (rows k with k % gridDim.x == blockIdx.x) for the backward pass, from the same registers.
+// NT threads; the caller puts a barrier behind it.
+template <int RT, bool BUILD, int CJ, int NT>
+__device__ __forceinline__ void stage_wn_planes(float* sm, const float* __restrict__ Wn, int64_t wn_stride,
+                                                const int64_t* __restrict__ labels, int way, int K, int n,
+                                                const WnBuild& wb) {
+    constexpr int C = 64 * CJ, NR = 32 * RT, LDD = (C + 8) / 2, NSL = C / 16, NW = NT / 64;
+    constexpr int NV = NR * C / 4, SU = (NV + NT - 1) / NT;        // 16-byte pieces, per thread
+    constexpr int cshift = CJ == 1 ? 6 : 8;
     const int tid = threadIdx.x;
-    if constexpr (BUILD) {
-        float* dst = wb.Wn_out + (int64_t)n * K * C;
-        for (int k = blockIdx.x; k < K; k += gridDim.x)
-            for (int c = tid; c < C; c += 256) dst[k * C + c] = sm[k * ldw + c];
-    }
-    constexpr int PER = NR * (C / 2) / 256;        // channel pairs per thread (48 at RT = 3, C = 256)
-    float v0[PER], v1[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
-        v0[q] = sm[row * ldw + 2 * cp];
-        v1[q] = sm[row * ldw + 2 * cp + 1];
-    }
-    __syncthreads();
     unsigned* pl = reinterpret_cast<unsigned*>(sm);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto put = [&](int k, int c, const f32x4& v) {                 // c: a multiple of 4
+        unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int i = q * 256 + tid, row = i / (C / 2), cp = i % (C / 2);
-        unsigned h0, m0, l0, h1, m1, l1;
-        split_bf16x3(v0[q], h0, m0, l0);
-        split_bf16x3(v1[q], h1, m1, l1);
-        pl[(0 * NR + row) * LDD + cp] = (h0 >> 16) | h1;
-        pl[(1 * NR + row) * LDD + cp] = (m0 >> 16) | m1;
-        pl[(2 * NR + row) * LDD + cp] = (l0 >> 16) | l1;
+        for (int e = 0; e < 4; ++e) split_bf16x3(v[e], h[e], m[e], l[e]);
+        unsigned* d = pl + k * LDD + (c >> 1);
+        *reinterpret_cast<u32x2*>(d) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+        *reinterpret_cast<u32x2*>(d + NR * LDD) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+        *reinterpret_cast<u32x2*>(d + 2 * NR * LDD) = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+    };
+    auto mine_row = [&](int k) { return (k % (int)gridDim.x) == (int)blockIdx.x; };
+    float* wout = BUILD ? wb.Wn_out + (int64_t)n * K * C : nullptr;
+    // the rows this episode's ways overwrite: thread group jw = tid / 64 sums the partials of way jw
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+    int pk = -1, pc = 0;
+    if constexpr (BUILD) {
+        const int jw = min(tid >> 6, way - 1), c4 = min(tid & 63, (C >> 2) - 1);
+        const int64_t* lab = labels + (int64_t)n * way;
+        const int64_t mine = lab[jw];
+        bool win = (tid >> 6) < way && (tid & 63) < (C >> 2) && mine >= 0 && mine < K;
+        for (int jj = jw + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
+        const float* pp = wb.proto_part + ((int64_t)(n * way + jw) * NSL) * C + c4 * 4;
+        f32x4 t[NSL];
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) t[q] = *reinterpret_cast<const f32x4*>(pp + (int64_t)q * C);
+        f32x4 acc4 = t[0];
+#pragma unroll
+        for (int q = 1; q < NSL; ++q) { acc4[0] += t[q][0]; acc4[1] += t[q][1]; acc4[2] += t[q][2]; acc4[3] += t[q][3]; }
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wb.bl + c4 * 4);
+        pv = f32x4{acc4[0] + b4[0], acc4[1] + b4[1], acc4[2] + b4[2], acc4[3] + b4[3]};
+        pk = win ? (int)mine : -1;
+        pc = c4 * 4;
     }
-    __syncthreads();
+    {
+        const float* src = BUILD ? wb.weight : Wn + (int64_t)n * wn_stride;
+        const float* msk = (BUILD && wb.weight_mask) ? wb.weight_mask + (int64_t)n * K * C : nullptr;
+        const int64_t* lab = labels + (int64_t)n * way;
+        const int nv = (K * C) >> 2;
+        f32x4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(u * NT + tid, nv - 1) * 4);
+        if (BUILD && msk != nullptr) {
+            f32x4 mm[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) mm[u] = *reinterpret_cast<const f32x4*>(msk + (int64_t)min(u * NT + tid, nv - 1) * 4);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { v[u][0] *= mm[u][0]; v[u][1] *= mm[u][1]; v[u][2] *= mm[u][2]; v[u][3] *= mm[u][3]; }
+        } else if (BUILD && wb.wdrop.on) {
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i4 = min(u * NT + tid, nv - 1);
+                const f32x4 m = drop_mult4(wb.wdrop, DENET_DROP_WEIGHT, (unsigned)(n * nv + i4));
+                v[u][0] *= m[0]; v[u][1] *= m[1]; v[u][2] *= m[2]; v[u][3] *= m[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i4 = u * NT + tid;
+            if (i4 < NV) {
+                const int idx = i4 * 4;
+                const int k = idx >> cshift, c = idx & (C - 1);
+                if (k >= K) {
+                    put(k, c, f32x4{0.f, 0.f, 0.f, 0.f});
+                } else {
+                    bool keep = true;                 // BUILD: the rows a way overwrites are written below
+                    if constexpr (BUILD)
+                        for (int jj = 0; jj < way; ++jj) keep = keep && (lab[jj] != k);
+                    if (keep) {
+                        put(k, c, v[u]);
+                        if (BUILD && mine_row(k)) *reinterpret_cast<f32x4*>(wout + k * C + c) = v[u];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BUILD) {
+        if (pk >= 0) {
+            put(pk, pc, pv);
+            if (mine_row(pk)) *reinterpret_cast<f32x4*>(wout + pk * C + pc) = pv;
+        }
+        // more than NW ways: the remaining ones, NW at a time (winners own distinct rows)
+        for (int jw0 = NW; jw0 < way; jw0 += NW) {
+            const int jw = jw0 + (tid >> 6), c4 = tid & 63;
+            if (jw < way && c4 < (C >> 2)) {
+                const int64_t* lab = labels + (int64_t)n * way;
+                const int64_t mine = lab[jw];
+                bool win = mine >= 0 && mine < K;
+                for (int jj = jw + 1; jj < way; ++jj) win = win && (lab[jj] != mine);
+                if (win) {
+                    const float* pp = wb.proto_part + ((int64_t)(n * way + jw) * NSL) * C + c4 * 4;
+                    f32x4 acc4 = *reinterpret_cast<const f32x4*>(pp);
+                    for (int q = 1; q < NSL; ++q) {
+                        const f32x4 tq = *reinterpret_cast<const f32x4*>(pp + (int64_t)q * C);
+                        acc4[0] += tq[0]; acc4[1] += tq[1]; acc4[2] += tq[2]; acc4[3] += tq[3];
+                    }
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(wb.bl + c4 * 4);
+                    const f32x4 r = {acc4[0] + b4[0], acc4[1] + b4[1], acc4[2] + b4[2], acc4[3] + b4[3]};
+                    put((int)mine, c4 * 4, r);
+                    if (mine_row((int)mine)) *reinterpret_cast<f32x4*>(wout + (int)mine * C + c4 * 4) = r;
+                }
+            }
+        }
+    }
 }
 
 #define CLB_LDS(RT, C) ((size_t)3 * 32 * (RT) * ((C) + 8) * 2)
@@ -313,7 +397,6 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
     const int n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    const int ldw = C + 1;
     const int ntile = (P + CL_TP - 1) / CL_TP;
     const int tile = blockIdx.x * 4 + wave;
     const bool active = tile < ntile;
@@ -324,16 +407,10 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
 
     STAMP(0);
     // Wn first (L2 hits, back in a round trip), THEN the Fq requests: vmcnt retires in order, so a wait on Wn
-    // behind 128 HBM loads would be a wait on all of them; this way the conversion below runs under the Fq stream
-    constexpr int SUc = RT == 1 ? 8 : RT == 2 ? 16 : 24;
-    stage_wn<BUILD, 256, C / 16, SUc>(sm, Wn, wn_stride, labels, way, K, C, n, wb);
-    for (int i = K * ldw + tid; i < NR * ldw; i += 256) sm[i] = 0.f;           // zero rows K .. 32 RT - 1
-    STAMP(1);
-    __builtin_amdgcn_sched_barrier(0);
-    // the wave's B operand: channel 16 q + 8 hh + i, positions pc, pc + 1 (unconditional, clamped), requested in
-    // two halves -- a wave keeps ~64 loads in flight, so asking for all C/2 at once stalls the issue for a round
-    // trip (3.5 us measured) before the conversion can start; the second half goes out after it, under the
-    // first half's MFMAs
+    // behind 128 HBM loads would be a wait on all of them.  The wave's B operand: channel 16 q + 8 hh + i,
+    // positions pc, pc + 1 (unconditional, clamped), requested in two halves -- a wave keeps ~64 loads in flight,
+    // so asking for all C/2 at once stalls the issue for a round trip; the second half goes out before the MFMAs
+    // of the first.
     unsigned x[KS][8];
     auto request = [&](int q0, int q1) {
 #pragma unroll
@@ -349,12 +426,13 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_bf16_kernel(const unsi
         __builtin_amdgcn_sched_barrier(0);
     };
     constexpr int KH = KS > 4 ? KS / 2 : KS;
+    stage_wn_planes<RT, BUILD, CJ, 256>(sm, Wn, wn_stride, labels, way, K, n, wb);
+    STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
     request(0, KH);
     STAMP(2);
-
     __syncthreads();
     STAMP(3);
-    wn_image_to_planes<RT, BUILD, CJ>(sm, wb, n, K);
     request(KH, KS);
     if (!active) return;                           // (no barrier below this line)
     STAMP(4);
