@@ -6,6 +6,9 @@
 tag=$1
 out=gpurun_out/profiles_out
 mkdir -p $out
+# heartbeat: a run that writes nothing for three minutes is taken to be hung (counter passes are quiet for long)
+( while sleep 45; do date +%T >> gpurun_out/heartbeat.txt; done ) &
+hb=$!
 prof() {   # prof <suffix> <config> <episodes> [bench args]
   local sfx=$1 cfg=$2 eps=$3; shift 3
   bash scripts/profile_bench.sh ${tag}_$sfx "$@" > gpurun_out/${tag}_${sfx}_profile.log 2>&1
@@ -38,5 +41,7 @@ for c in c2 c3 c5; do
   python3 scripts/counter_fold.py "LDS counters, $C" gpurun_out/lds_${tag}_$c >> $out/${tag}_sq_counters.txt
   rm -rf gpurun_out/sq_${tag}_$c gpurun_out/lds_${tag}_$c gpurun_out/sq_${tag}_$c.log gpurun_out/lds_${tag}_$c.log
 done
+kill $hb 2>/dev/null
+rm -f gpurun_out/heartbeat.txt
 du -sh gpurun_out
 echo done
