@@ -252,17 +252,7 @@ __global__ __launch_bounds__(256) void classify_fwd_wide4_kernel(const T* __rest
 // LDS: 3 x 32 RT x (C + 8) x 2 B = 152 KB at RT = 3 (the planes are written straight from the global loads,
 // stage_wn_planes: no fp32 image in between).
 // ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// w = hi + mid + lo, each a bf16 (returned in the high half of a dword); exact for finite w
-__device__ __forceinline__ void split_bf16x3(float w, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(w) & 0xffff0000u;
-    const float r1 = w - __uint_as_float(h);               // <= 16 significant bits
-    m = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m);              // <= 8 significant bits
-    l = __float_as_uint(r2) & 0xffff0000u;
-}
+// (bf16x8, u32x4, split_bf16x3: dev_classify.hpp)
 
 // Wn[n] from global memory straight into the three bf16 planes (no fp32 image, no second pass through LDS): the
 // loads, row selection and dropout of stage_wn, then split_bf16x3 on the loaded registers and 8-byte plane

@@ -10,6 +10,21 @@ typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned short u16x2_u __attribute__((ext_vector_type(2), aligned(2)));
 
+// bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): operand fragments are 8 bf16 = 4 dwords per lane
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_u2 __attribute__((ext_vector_type(4), aligned(2)));     // 8 bf16 at any element address
+
+// w = hi + mid + lo, each a bf16 (returned in the high half of a dword); exact for finite w
+__device__ __forceinline__ void split_bf16x3(float w, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(h);               // <= 16 significant bits
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);              // <= 8 significant bits
+    l = __float_as_uint(r2) & 0xffff0000u;
+}
+
 // ---------------------------------------------------------------------------
 // K3b: backward.  One block per (episode, 64-position tile), NW waves:
 //   dL[k][p]   = scale[n] * (dlog_a + dlog_b)                     -> LDS
@@ -528,6 +543,316 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
                         a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][0], a0, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * gi + q], Bf[gi & 1][q][1], a1, 0, 0, 0);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s0 = a0;
+            s1 = a1;
+            ts = t;
+        }
+        if (t - t0 < 4) WSTAMP(4 + 4 * (t - t0));
+        store_dl(nxt, tn, va, vb, sc);
+        __syncthreads();
+        if (t - t0 < 4) WSTAMP(5 + 4 * (t - t0));
+    }
+    WSTAMP(30);
+
+    if constexpr (DWN) {
+        if (have) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kr = 32 * rt + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (kr < K) dWn_part[(((int64_t)n * ngrp + grp) * K + kr) * C + ct * 32 + j] = acc[rt][e];
+                }
+        }
+    } else {
+        if (have && ts >= 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) store_dfq_e(ts, e, s0[e], s1[e]);
+        }
+    }
+    WSTAMP(31);
+    BSTAMP(1);
+}
+
+// ---------------------------------------------------------------------------
+// The persistent backward for bf16 features with 32 < K <= 96, on the bf16 matrix pipe (round 3).  Same blocks,
+// roles, tile loop, double-buffered dL and load / store interleaving as classify_bwd_wide_body; what changes is
+// the arithmetic and what it lets go of.  dL = scale * (dlog_a + dlog_b) is split into bf16 planes when it goes
+// to LDS (dL = h + m + l exactly, split_bf16x3), Fq is bf16 already:
+//   role dWn:  dWn[k][c] += sum_p dL[k][p] Fq[c][p]: the contraction runs over POSITIONS, and eight consecutive
+//              positions of a channel row are 16 contiguous bytes of Fq -- the B fragment is ONE global load per
+//              lane and k-step, no transposition tile in LDS (the fp32 kernel turns every Fq tile through LDS:
+//              lane <-> channel for the MFMA, lane <-> position for memory).  A = dL planes [3][32 RT][72] bf16
+//              (144-byte rows: sixteen lanes' 16-byte reads cover the 64 banks).  3 planes x RT x 4 k-steps =
+//              36 MFMAs of 32 cycles per tile and wave instead of 96 of 64; every product is exact.
+//   role dFq:  dFq[c][p] = sum_k Wn[k][c] dL[k][p]: the contraction runs over CLASSES, so dL goes to LDS
+//              transposed, [2][64 positions][32 RT + 8] bf16 (row of position p = 32 (p & 1) + (p >> 1): the two
+//              column tiles of the MFMA are the even and the odd positions, which keeps dFq's 4-byte pair stores),
+//              and Wn^T sits in registers as two planes, split once per block.  dFq leaves as bf16 (8 significand
+//              bits), so the terms of order <= 1 suffice: Wh dh + Wh dm + Wm dh, error < 2^-15 of a product;
+//              3 x 2 RT k-steps x 2 tiles = 36 MFMAs per tile and wave instead of 96.
+// Measured with the MFMAs taken out of the fp32 kernel (-DDENET_DIAG_BW_NOMFMA): B1 65.8 -> 38 us at C5, i.e. the
+// matrix work was 27 us of the launch.
+// ---------------------------------------------------------------------------
+#define CLWB_LDP 72                                  // bf16 per row of the [class][position] planes (dWn role)
+#define CLWB_LDK(RT) (32 * (RT) + 8)                 // bf16 per row of the [position][class] planes (dFq role)
+#define CLWB_BUF_DWN(RT) (3 * 32 * (RT) * CLWB_LDP)  // bf16 elements per buffer
+#define CLWB_BUF_DFQ(RT) (2 * 64 * CLWB_LDK(RT))
+#define CLWB_BUF(RT) (CLWB_BUF_DWN(RT) > CLWB_BUF_DFQ(RT) ? CLWB_BUF_DWN(RT) : CLWB_BUF_DFQ(RT))
+#define CLWB_LDS(RT) ((size_t)2 * CLWB_BUF(RT) * 2)
+
+// elements i + sh of a fragment of 8 bf16, zeros from the end (sh >= 8: all zeros): the fragment was loaded
+// `sh` positions before the ones it stands for, because those run past the end of the row
+__device__ __forceinline__ u32x4 bf16x8_shift_down(const u32x4 v, int sh) {
+    unsigned long long lo = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+    unsigned long long hi = (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
+    const int s = 16 * sh;
+    if (s >= 128) { lo = 0ull; hi = 0ull; }
+    else if (s >= 64) { lo = hi >> (s - 64); hi = 0ull; }
+    else if (s > 0) { lo = (lo >> s) | (hi << (64 - s)); hi >>= s; }
+    return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+}
+
+template <int RT, bool DWN, bool NTQ = false>
+__device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g, int n, int grp, float* smf) {
+    typedef unsigned short T;
+    const T* __restrict__ Fq = reinterpret_cast<const T*>(g.Fq);
+    const float* __restrict__ dlog_a = g.dlog_a;
+    const float* __restrict__ dlog_b = g.dlog_b;
+    T* __restrict__ dFq = reinterpret_cast<T*>(g.dFq);
+    float* __restrict__ dWn_part = g.dWn_part;
+    const int K = g.K, C = g.C, P = g.P, ngrp = g.n_part;
+    constexpr int NT = CLW_BWD_NW * 64, NR = 32 * RT, KS = 2 * RT;      // KS: class k-steps of 16 (dFq role)
+    constexpr int LDP = CLWB_LDP, LDK = CLWB_LDK(RT), BUF = CLWB_BUF(RT);
+    const int ntile = (P + CL_TP - 1) / CL_TP;
+    const int t0 = (int)((int64_t)grp * ntile / ngrp), t1 = (int)((int64_t)(grp + 1) * ntile / ngrp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const float* wn = g.Wn + (int64_t)n * K * C;
+    const int ct = wave;
+    const bool have = ct < (C >> 5);               // C = 64: waves 2.. only help with the staging
+    const int cc = min(ct, (C >> 5) - 1);
+    unsigned short* sm = reinterpret_cast<unsigned short*>(smf);
+    unsigned short* dl0 = sm;
+    unsigned short* dl1 = sm + BUF;
+    // what store_dl never writes stays zero: class rows (dWn role) / class columns (dFq role) K .. 32 RT - 1
+    if constexpr (DWN) {
+        for (int idx = tid; idx < 2 * 3 * (NR - K) * LDP; idx += NT) {
+            const int per = (NR - K) * LDP, q = idx / per, r = idx - q * per;      // q = buffer * 3 + plane
+            sm[(q / 3) * BUF + ((q % 3) * NR + K) * LDP + r] = 0;
+        }
+    } else {
+        for (int idx = tid; idx < 2 * 2 * 64 * (NR - K); idx += NT) {
+            const int per = NR - K, q = idx / per, r = idx - q * per;              // q = (buffer * 2 + plane) * 64 + row
+            sm[(q >> 7) * BUF + (q & 127) * LDK + K + r] = 0;
+        }
+    }
+
+    const bool have_b = dlog_b != nullptr;
+    const float* __restrict__ dlb = have_b ? dlog_b : dlog_a;      // no branch around a load
+    // dL staging as in classify_bwd_wide_body: thread <-> RT quads (row k = idx >> 4, four positions 4 * (idx & 15)),
+    // every quad load starts at min(p, P - 4), the lanes whose quad was moved back pick their elements (quad_fix)
+    auto quad_fix = [&](const f32x4& l, int sh) {
+        f32x4 r;
+        r[0] = sh == 0 ? l[0] : sh == 1 ? l[1] : sh == 2 ? l[2] : sh == 3 ? l[3] : 0.f;
+        r[1] = sh == 0 ? l[1] : sh == 1 ? l[2] : sh == 2 ? l[3] : 0.f;
+        r[2] = sh == 0 ? l[2] : sh == 1 ? l[3] : 0.f;
+        r[3] = sh == 0 ? l[3] : 0.f;
+        return r;
+    };
+    auto load_dl_u = [&](int tile, int u, f32x4& xa, f32x4& xb) {
+        const int idx = u * NT + tid;
+        const int k = min(idx >> 4, K - 1), pq = min(tile * CL_TP + 4 * (idx & 15), P - 4);
+        const f32x4_u a = *reinterpret_cast<const f32x4_u*>(dlog_a + ((int64_t)n * K + k) * P + pq);
+        const f32x4_u b = *reinterpret_cast<const f32x4_u*>(dlb + ((int64_t)n * K + k) * P + pq);
+        xa = f32x4{a[0], a[1], a[2], a[3]};
+        xb = f32x4{b[0], b[1], b[2], b[3]};
+    };
+    auto store_dl = [&](unsigned short* buf, int tile, const f32x4 (&va)[RT], const f32x4 (&vb)[RT], float sc) {
+        const bool part = (tile + 1) * CL_TP > P;          // uniform
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            const int idx = u * NT + tid, k = idx >> 4, q4 = 4 * (idx & 15);
+            if (k < K) {
+                const int pq = tile * CL_TP + q4;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (va[u][e] + (have_b ? vb[u][e] : 0.f)) * sc;
+                if (part) v = quad_fix(v, pq - min(pq, P - 4));
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_bf16x3(v[e], h[e], m[e], l[e]);
+                if constexpr (DWN) {
+                    unsigned short* d = buf + k * LDP + q4;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+                    *reinterpret_cast<u32x2*>(d + NR * LDP) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+                    *reinterpret_cast<u32x2*>(d + 2 * NR * LDP) = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int p = q4 + e, row = 32 * (p & 1) + (p >> 1);
+                        buf[row * LDK + k] = (unsigned short)(h[e] >> 16);
+                        buf[(64 + row) * LDK + k] = (unsigned short)(m[e] >> 16);
+                    }
+                }
+            }
+        }
+    };
+    // dWn role, B fragment of k-step ks of a tile: 8 positions of channel cc*32 + j from tile*64 + 16 ks + 8 hh on.
+    // The load starts at min(position, P - 8) (always inside the row); fq_fix shifts the fragment and zeroes the
+    // positions past P (partial last tile of an episode only).
+    const T* fqrow = Fq + ((int64_t)n * C + cc * 32 + j) * P;
+    auto load_fq = [&](int tile, int ks) {
+        const int p0 = tile * CL_TP + 16 * ks + 8 * hh;
+        const u32x4_u2 v = *reinterpret_cast<const u32x4_u2*>(fqrow + max(min(p0, P - 8), 0));
+        return u32x4{v[0], v[1], v[2], v[3]};
+    };
+    auto fq_fix = [&](int tile, int ks, const u32x4 v) {
+        const int p0 = tile * CL_TP + 16 * ks + 8 * hh;
+        return bf16x8_shift_down(v, p0 - min(p0, P - 8));
+    };
+    auto store_dfq_e = [&](int tile, int e, float x0, float x1) {
+        const int pa = tile * CL_TP + 2 * j;
+        const int c = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        T* dst = dFq + ((int64_t)n * C + c) * P + pa;
+        if (pa + 1 < P) {
+            const u16x2_u v = {f32_to_bf16(x0), f32_to_bf16(x1)};
+            if constexpr (NTQ) __builtin_nontemporal_store(v, reinterpret_cast<u16x2_u*>(dst));
+            else *reinterpret_cast<u16x2_u*>(dst) = v;
+        } else if (pa < P) {
+            FeatIO<T>::store(dst, x0);
+        }
+    };
+
+    // everything this block needs first is requested before the first wait
+    f32x4 va[RT], vb[RT];
+    u32x4 fqn[DWN ? 4 : 1];
+    u32x4 wa[DWN ? 1 : KS][2];
+    WSTAMP(0);
+    BSTAMP(0);
+    float de = 0.f;
+    if (g.part_k != nullptr) de = part_k_lane(g.part_k, g.parts_k, n);
+#pragma unroll
+    for (int u = 0; u < RT; ++u) load_dl_u(t0, u, va[u], vb[u]);
+    if constexpr (DWN) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fqn[ks] = load_fq(t0, ks);
+    } else {
+        // Wn^T as two bf16 planes: lane (channel cc*32 + j, half hh) holds classes 16 ks + 8 hh + i
+        float w[KS][8];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = 16 * ks + 8 * hh + i;
+                const float v = wn[(int64_t)min(kk, K - 1) * C + cc * 32 + j];
+                w[ks][i] = kk < K ? v : 0.f;
+            }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned h[8], m[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_bf16x3(w[ks][i], h[i], m[i], l[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wa[ks][0][q] = (h[2 * q] >> 16) | h[2 * q + 1];
+                wa[ks][1][q] = (m[2 * q] >> 16) | m[2 * q + 1];
+            }
+        }
+    }
+    float sc;
+    if (g.part_k != nullptr) {
+        sc = 1.f / ((float)g.N * wave_sum(de));
+        if (g.scale_out != nullptr && grp == 0 && tid == 0) g.scale_out[n] = sc;
+    } else {
+        sc = g.scale ? g.scale[n] : 1.f;
+    }
+    sc *= (g.gmul ? g.gmul[0] : 1.f);
+    store_dl(dl0, t0, va, vb, sc);
+    __syncthreads();
+    WSTAMP(1);
+
+    f32x16 acc[DWN ? RT : 1];
+    if constexpr (DWN) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+    }
+    // dFq: the finished tile waits in s0 / s1 and is stored between the MFMAs of the next tile
+    f32x16 s0, s1;
+    int ts = -1;                                    // tile held in s0 / s1 (-1: none)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        const unsigned short* cur = ((t - t0) & 1) ? dl1 : dl0;
+        unsigned short* nxt = ((t - t0) & 1) ? dl0 : dl1;
+        const int tn = min(t + 1, t1 - 1);
+        if (t - t0 < 4) WSTAMP(2 + 4 * (t - t0));
+        if constexpr (DWN) {
+            u32x4 fqc[4];
+            const bool part = (t + 1) * CL_TP > P;         // uniform
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fqc[ks] = part ? fq_fix(t, ks, fqn[ks]) : fqn[ks];
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short* arow = cur + j * LDP + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 A[3][RT];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        A[s][rt] = *reinterpret_cast<const u32x4*>(arow + (s * NR + 32 * rt) * LDP + 16 * ks);
+                // the loads of tile t+1, a few per k-step (see classify_bwd_wide_body)
+                if (ks < RT) load_dl_u(tn, ks, va[ks], vb[ks]);
+                fqn[ks] = load_fq(tn, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) {
+                    const bf16x8 B = __builtin_bit_cast(bf16x8, fqc[ks]);
+#pragma unroll
+                    for (int s = 2; s >= 0; --s)           // smallest plane first
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s][rt]), B,
+                                                                              acc[rt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+            const unsigned short* brow = cur + j * LDK + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // B = dL^T planes: rows of the even (tile 0) and odd (tile 1) positions, classes 16 ks + 8 hh ..
+                u32x4 Bf[2][2];                    // [plane][tile]
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        Bf[s][tt] = *reinterpret_cast<const u32x4*>(brow + (s * 64 + 32 * tt) * LDK + 16 * ks);
+                if (ks < RT) load_dl_u(tn, ks, va[ks], vb[ks]);
+                if (have && ts >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if ((e * KS) / 16 == ks) store_dfq_e(ts, e, s0[e], s1[e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (have && 16 * ks < K) {
+                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, wa[ks][0]), Am = __builtin_bit_cast(bf16x8, wa[ks][1]);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, __builtin_bit_cast(bf16x8, Bf[0][0]), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, __builtin_bit_cast(bf16x8, Bf[0][1]), a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[1][0]), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[1][1]), a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[0][0]), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[0][1]), a1, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -3,6 +3,8 @@
 // (trainer/trainers.py:951-975), i.e. K0..K5 forward and K4b..K1b backward, on
 // one stream, with a caller-provided workspace and no host synchronisation
 // (the reference syncs N*way + 3 times per step: SURVEY.md §1).
+#include <type_traits>
+
 #include "denet_common.hpp"
 #include "dev_chain_sliced.hpp"
 #include "dev_classify.hpp"
@@ -94,6 +96,24 @@ __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsB
     }
 }
 
+// bf16 features, 32 < K <= 96: the same blocks on the bf16 matrix pipe (dev_classify.hpp, classify_bwd_wide_bf16_body)
+template <int RT, bool NTQ>
+__global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_bf16_kernel(ClsBwdArgs g, ClsBwdArgs g2,
+                                                                                 const float* __restrict__ part_p, int NB,
+                                                                                 int parts_p, float* __restrict__ losses) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ngrp = g.n_part;
+    if ((int)blockIdx.x < ngrp) {
+        classify_bwd_wide_bf16_body<RT, true>(g, blockIdx.y, blockIdx.x, sm);
+        if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+            __syncthreads();
+            loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
+        }
+    } else {
+        classify_bwd_wide_bf16_body<RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+    }
+}
+
 template <int CJ, int NS>
 __global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a, PeParamsArgs pa, int nchain) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -125,6 +145,13 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
 #endif
 // the backward launchers' choices, from the call's sizes alone (also reported by denet_head_step_plan)
 static inline bool bwd_persistent(int64_t P) { return P >= 4; }       // quad loads need P >= 4
+#ifndef DENET_BWD_BF16_PIPE
+#define DENET_BWD_BF16_PIPE 1
+#endif
+// bf16 features with 32 < K <= 96 run B1 on the bf16 matrix pipe (its 16-byte Fq fragments need rows of >= 8)
+static inline bool bwd_bf16_pipe(int64_t K, int64_t P, size_t sF) {
+    return DENET_BWD_BF16_PIPE && sF == 2 && K > 32 && K <= 96 && P >= 8;
+}
 static inline bool bwd_dfq_nt(int64_t N, int64_t C, int64_t P, size_t sF) {
     return N * C * P * (int64_t)sF <= ((int64_t)DENET_DFQ_NT_MB << 20);
 }
@@ -142,6 +169,24 @@ static inline bool dfs_chunked(bool nt, bool f32) { return DENET_DFS_CHUNKED && 
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
+    if constexpr (std::is_same<T, unsigned short>::value && (RT == 2 || RT == 3)) {
+        if (wide && bwd_bf16_pipe(g.K, g.P, sizeof(T))) {
+            // (the finalize body of block (0, 0) reuses the LDS: both allocations are far above what it needs)
+            const size_t ldb = CLWB_LDS(RT);
+            if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
+                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<RT, true>), ldb))
+                    return DENET_E_LAUNCH;
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
+            } else {
+                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<RT, false>), ldb))
+                    return DENET_E_LAUNCH;
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
+            }
+            return DENET_OK;
+        }
+    }
     if (wide) {                         // persistent blocks (quad loads need P >= 4; see cls_bwd_parts below)
         const size_t ldw = CLW_BWD_LDS(RT);
         if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
@@ -249,6 +294,7 @@ extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_
     p.bwd_persistent = bwd_persistent(P);
     p.bwd_groups = p.bwd_persistent ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
     p.bwd_dfq_nt = p.bwd_persistent && bwd_dfq_nt(N, C, P, sF);
+    p.bwd_bf16_pipe = p.bwd_persistent && bwd_bf16_pipe(K, P, sF);
     p.dfs_nt = dfs_nt(B, C, P, sF);
     // non-temporal streams: fp32 = the flat span writer inside B3, bf16 = coefficient blocks + dfs_chunk_kernel
     p.dfs_chunked = dfs_chunked(p.dfs_nt, sF == 4);

@@ -176,8 +176,8 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
 
 def test_c5_at_the_benchmarked_batch(dev):
     """C5 at the 8 episodes profiles/*_bench_c5.json times (the N = 2 case above stays below every size
-    threshold): long-row bf16 pooling with non-temporal loads (269 MB), flat mask resize, classifier layout (b),
-    chain loss kernel on 9-column cells, persistent backward with 15 tile groups, the chunked bf16 dFs writer
+    threshold): long-row bf16 pooling with non-temporal loads (269 MB), flat mask resize, the bf16-pipe classifier,
+    chain loss kernel on 9-column cells, persistent backward with 15 tile groups on the bf16 matrix pipe, the chunked bf16 dFs writer
     (coefficient blocks + one block per contiguous chunk, non-temporal stores)."""
     from denet_amd import _lib
     from denet_amd.synthetic import CONFIGS
@@ -187,7 +187,7 @@ def test_c5_at_the_benchmarked_batch(dev):
     assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 1
     assert pl["classify_layout"] == _lib.CLS_WAVE4_BF16
     assert pl["loss_chain_cell"] == 9
-    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 15 and pl["bwd_dfq_nt"] == 1
+    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 15 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 0 and pl["dfs_chunked"] == 1
     ep, out = _check_step_against_oracle(s, dev, 8e-3)
     assert out["Fs"].grad.dtype == torch.bfloat16
