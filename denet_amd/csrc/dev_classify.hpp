@@ -1,6 +1,8 @@
 // Device body of K3b (classifier backward), shared by the stand-alone kernel (classify.hip) and the
 // fused step kernels (head_step.hip).
 #pragma once
+#include <type_traits>
+
 #include "denet_common.hpp"
 
 #define CL_TP 64          // positions per block
@@ -600,7 +602,7 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
 #define CLWB_LDP 72                                  // bf16 per row of the [class][position] planes (dWn role)
 #define CLWB_LDK(RT) (32 * (RT) + 8)                 // bf16 per row of the [position][class] planes (dFq role)
 #define CLWB_BUF_DWN(RT) (3 * 32 * (RT) * CLWB_LDP)  // bf16 elements per buffer
-#define CLWB_BUF_DFQ(RT) (2 * 64 * CLWB_LDK(RT))
+#define CLWB_BUF_DFQ(RT) (3 * 64 * CLWB_LDK(RT))   // (two planes for bf16 features, three for fp32)
 #define CLWB_BUF(RT) (CLWB_BUF_DWN(RT) > CLWB_BUF_DFQ(RT) ? CLWB_BUF_DWN(RT) : CLWB_BUF_DFQ(RT))
 #define CLWB_LDS(RT) ((size_t)2 * CLWB_BUF(RT) * 2)
 
@@ -616,9 +618,10 @@ __device__ __forceinline__ u32x4 bf16x8_shift_down(const u32x4 v, int sh) {
     return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
 }
 
-template <int RT, bool DWN, bool NTQ = false>
+template <typename T, int RT, bool DWN, bool NTQ = false>
 __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g, int n, int grp, float* smf) {
-    typedef unsigned short T;
+    constexpr bool F32 = sizeof(T) == 4;           // fp32 features: Fq is split in registers, all six terms of order <= 2
+    constexpr int NPQ = F32 ? 3 : 2;               // planes of dL^T and Wn^T in the dFq role
     const T* __restrict__ Fq = reinterpret_cast<const T*>(g.Fq);
     const float* __restrict__ dlog_a = g.dlog_a;
     const float* __restrict__ dlog_b = g.dlog_b;
@@ -627,6 +630,7 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
     const int K = g.K, C = g.C, P = g.P, ngrp = g.n_part;
     constexpr int NT = CLW_BWD_NW * 64, NR = 32 * RT, KS = 2 * RT;      // KS: class k-steps of 16 (dFq role)
     constexpr int LDP = CLWB_LDP, LDK = CLWB_LDK(RT), BUF = CLWB_BUF(RT);
+    static_assert(NPQ * 64 * CLWB_LDK(RT) <= CLWB_BUF(RT), "dFq-role planes must fit the buffer");
     const int ntile = (P + CL_TP - 1) / CL_TP;
     const int t0 = (int)((int64_t)grp * ntile / ngrp), t1 = (int)((int64_t)(grp + 1) * ntile / ngrp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -645,9 +649,9 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
             sm[(q / 3) * BUF + ((q % 3) * NR + K) * LDP + r] = 0;
         }
     } else {
-        for (int idx = tid; idx < 2 * 2 * 64 * (NR - K); idx += NT) {
-            const int per = NR - K, q = idx / per, r = idx - q * per;              // q = (buffer * 2 + plane) * 64 + row
-            sm[(q >> 7) * BUF + (q & 127) * LDK + K + r] = 0;
+        for (int idx = tid; idx < 2 * NPQ * 64 * (NR - K); idx += NT) {
+            const int per = NR - K, q = idx / per, r = idx - q * per;              // q = buffer * (NPQ * 64) + plane * 64 + row
+            sm[(q / (NPQ * 64)) * BUF + (q % (NPQ * 64)) * LDK + K + r] = 0;
         }
     }
 
@@ -696,6 +700,7 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
                         const int p = q4 + e, row = 32 * (p & 1) + (p >> 1);
                         buf[row * LDK + k] = (unsigned short)(h[e] >> 16);
                         buf[(64 + row) * LDK + k] = (unsigned short)(m[e] >> 16);
+                        if constexpr (NPQ == 3) buf[(128 + row) * LDK + k] = (unsigned short)(l[e] >> 16);
                     }
                 }
             }
@@ -703,25 +708,67 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
     };
     // dWn role, B fragment of k-step ks of a tile: 8 positions of channel cc*32 + j from tile*64 + 16 ks + 8 hh on.
     // The load starts at min(position, P - 8) (always inside the row); fq_fix shifts the fragment and zeroes the
-    // positions past P (partial last tile of an episode only).
+    // positions past P (partial last tile of an episode only).  bf16: the 16 bytes ARE the fragment; fp32: 32 bytes,
+    // split into three bf16 planes when the tile becomes current.
+    typedef typename std::conditional<F32, f32x4, u32x4>::type fqraw_t;
+    constexpr int NFR = F32 ? 2 : 1;               // raw vectors per k-step
     const T* fqrow = Fq + ((int64_t)n * C + cc * 32 + j) * P;
-    auto load_fq = [&](int tile, int ks) {
+    auto load_fq = [&](int tile, int ks, fqraw_t (&r)[NFR]) {
         const int p0 = tile * CL_TP + 16 * ks + 8 * hh;
-        const u32x4_u2 v = *reinterpret_cast<const u32x4_u2*>(fqrow + max(min(p0, P - 8), 0));
-        return u32x4{v[0], v[1], v[2], v[3]};
+        const T* src = fqrow + max(min(p0, P - 8), 0);
+        if constexpr (F32) {
+            const f32x4_u v0 = *reinterpret_cast<const f32x4_u*>(src), v1 = *reinterpret_cast<const f32x4_u*>(src + 4);
+            r[0] = f32x4{v0[0], v0[1], v0[2], v0[3]};
+            r[1] = f32x4{v1[0], v1[1], v1[2], v1[3]};
+        } else {
+            const u32x4_u2 v = *reinterpret_cast<const u32x4_u2*>(src);
+            r[0] = u32x4{v[0], v[1], v[2], v[3]};
+        }
     };
-    auto fq_fix = [&](int tile, int ks, const u32x4 v) {
-        const int p0 = tile * CL_TP + 16 * ks + 8 * hh;
-        return bf16x8_shift_down(v, p0 - min(p0, P - 8));
+    // -> the k-step's B planes (bf16: one; fp32: hi / mid / lo)
+    auto fq_planes = [&](int tile, int ks, const fqraw_t (&r)[NFR], bool part, u32x4 (&b)[F32 ? 3 : 1]) {
+        const int p0 = tile * CL_TP + 16 * ks + 8 * hh, sh = p0 - min(p0, P - 8);
+        if constexpr (F32) {
+            float x[8] = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+            if (part) {                             // uniform
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; i + q < 8; ++q) v = sh == q ? x[i + q] : v;
+                    y[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = y[i];
+            }
+            unsigned h[8], m[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_bf16x3(x[i], h[i], m[i], l[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b[0][q] = (h[2 * q] >> 16) | h[2 * q + 1];
+                b[1][q] = (m[2 * q] >> 16) | m[2 * q + 1];
+                b[2][q] = (l[2 * q] >> 16) | l[2 * q + 1];
+            }
+        } else {
+            b[0] = part ? bf16x8_shift_down(r[0], sh) : r[0];
+        }
     };
     auto store_dfq_e = [&](int tile, int e, float x0, float x1) {
         const int pa = tile * CL_TP + 2 * j;
         const int c = ct * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         T* dst = dFq + ((int64_t)n * C + c) * P + pa;
         if (pa + 1 < P) {
-            const u16x2_u v = {f32_to_bf16(x0), f32_to_bf16(x1)};
-            if constexpr (NTQ) __builtin_nontemporal_store(v, reinterpret_cast<u16x2_u*>(dst));
-            else *reinterpret_cast<u16x2_u*>(dst) = v;
+            if constexpr (F32) {
+                const f32x2_u v = {x0, x1};
+                if constexpr (NTQ) __builtin_nontemporal_store(v, reinterpret_cast<f32x2_u*>(dst));
+                else *reinterpret_cast<f32x2_u*>(dst) = v;
+            } else {
+                const u16x2_u v = {f32_to_bf16(x0), f32_to_bf16(x1)};
+                if constexpr (NTQ) __builtin_nontemporal_store(v, reinterpret_cast<u16x2_u*>(dst));
+                else *reinterpret_cast<u16x2_u*>(dst) = v;
+            }
         } else if (pa < P) {
             FeatIO<T>::store(dst, x0);
         }
@@ -729,8 +776,8 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
 
     // everything this block needs first is requested before the first wait
     f32x4 va[RT], vb[RT];
-    u32x4 fqn[DWN ? 4 : 1];
-    u32x4 wa[DWN ? 1 : KS][2];
+    fqraw_t fqn[DWN ? 4 : 1][NFR];
+    u32x4 wa[DWN ? 1 : KS][NPQ];
     WSTAMP(0);
     BSTAMP(0);
     float de = 0.f;
@@ -739,7 +786,7 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
     for (int u = 0; u < RT; ++u) load_dl_u(t0, u, va[u], vb[u]);
     if constexpr (DWN) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fqn[ks] = load_fq(t0, ks);
+        for (int ks = 0; ks < 4; ++ks) load_fq(t0, ks, fqn[ks]);
     } else {
         // Wn^T as two bf16 planes: lane (channel cc*32 + j, half hh) holds classes 16 ks + 8 hh + i
         float w[KS][8];
@@ -760,6 +807,7 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
             for (int q = 0; q < 4; ++q) {
                 wa[ks][0][q] = (h[2 * q] >> 16) | h[2 * q + 1];
                 wa[ks][1][q] = (m[2 * q] >> 16) | m[2 * q + 1];
+                if constexpr (NPQ == 3) wa[ks][2][q] = (l[2 * q] >> 16) | l[2 * q + 1];
             }
         }
     }
@@ -795,10 +843,11 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
         const int tn = min(t + 1, t1 - 1);
         if (t - t0 < 4) WSTAMP(2 + 4 * (t - t0));
         if constexpr (DWN) {
-            u32x4 fqc[4];
+            constexpr int NB = F32 ? 3 : 1;
+            u32x4 fqc[4][NB];
             const bool part = (t + 1) * CL_TP > P;         // uniform
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fqc[ks] = part ? fq_fix(t, ks, fqn[ks]) : fqn[ks];
+            for (int ks = 0; ks < 4; ++ks) fq_planes(t, ks, fqn[ks], part, fqc[ks]);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned short* arow = cur + j * LDP + 8 * hh;
 #pragma unroll
@@ -811,16 +860,18 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
                         A[s][rt] = *reinterpret_cast<const u32x4*>(arow + (s * NR + 32 * rt) * LDP + 16 * ks);
                 // the loads of tile t+1, a few per k-step (see classify_bwd_wide_body)
                 if (ks < RT) load_dl_u(tn, ks, va[ks], vb[ks]);
-                fqn[ks] = load_fq(tn, ks);
+                load_fq(tn, ks, fqn[ks]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (have) {
-                    const bf16x8 B = __builtin_bit_cast(bf16x8, fqc[ks]);
-#pragma unroll
-                    for (int s = 2; s >= 0; --s)           // smallest plane first
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-                            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[s][rt]), B,
-                                                                              acc[rt], 0, 0, 0);
+#define CLWB_TERM(SA, SB)                                                                                       \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
+        __builtin_bit_cast(bf16x8, A[SA][rt]), __builtin_bit_cast(bf16x8, fqc[ks][SB]), acc[rt], 0, 0, 0);
+                    if constexpr (F32) {           // dL plane x Fq plane, smallest terms first
+                        CLWB_TERM(1, 1) CLWB_TERM(2, 0) CLWB_TERM(0, 2) CLWB_TERM(1, 0) CLWB_TERM(0, 1) CLWB_TERM(0, 0)
+                    } else {
+                        CLWB_TERM(2, 0) CLWB_TERM(1, 0) CLWB_TERM(0, 0)
+                    }
+#undef CLWB_TERM
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -832,9 +883,9 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 // B = dL^T planes: rows of the even (tile 0) and odd (tile 1) positions, classes 16 ks + 8 hh ..
-                u32x4 Bf[2][2];                    // [plane][tile]
+                u32x4 Bf[NPQ][2];                  // [plane][tile]
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < NPQ; ++s)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
                         Bf[s][tt] = *reinterpret_cast<const u32x4*>(brow + (s * 64 + 32 * tt) * LDK + 16 * ks);
@@ -846,13 +897,17 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (have && 16 * ks < K) {
-                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, wa[ks][0]), Am = __builtin_bit_cast(bf16x8, wa[ks][1]);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, __builtin_bit_cast(bf16x8, Bf[0][0]), a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, __builtin_bit_cast(bf16x8, Bf[0][1]), a1, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[1][0]), a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[1][1]), a1, 0, 0, 0);
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[0][0]), a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, __builtin_bit_cast(bf16x8, Bf[0][1]), a1, 0, 0, 0);
+#define CLWB_TERM(SA, SB)                                                                                       \
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ks][SA]),                        \
+                                                 __builtin_bit_cast(bf16x8, Bf[SB][0]), a0, 0, 0, 0);           \
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ks][SA]),                        \
+                                                 __builtin_bit_cast(bf16x8, Bf[SB][1]), a1, 0, 0, 0);
+                    if constexpr (F32) {           // Wn plane x dL plane, smallest terms first
+                        CLWB_TERM(1, 1) CLWB_TERM(2, 0) CLWB_TERM(0, 2) CLWB_TERM(1, 0) CLWB_TERM(0, 1) CLWB_TERM(0, 0)
+                    } else {
+                        CLWB_TERM(1, 0) CLWB_TERM(0, 1) CLWB_TERM(0, 0)
+                    }
+#undef CLWB_TERM
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

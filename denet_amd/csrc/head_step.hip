@@ -97,20 +97,20 @@ __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsB
 }
 
 // bf16 features, 32 < K <= 96: the same blocks on the bf16 matrix pipe (dev_classify.hpp, classify_bwd_wide_bf16_body)
-template <int RT, bool NTQ>
+template <typename T, int RT, bool NTQ>
 __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_bf16_kernel(ClsBwdArgs g, ClsBwdArgs g2,
                                                                                  const float* __restrict__ part_p, int NB,
                                                                                  int parts_p, float* __restrict__ losses) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ngrp = g.n_part;
     if ((int)blockIdx.x < ngrp) {
-        classify_bwd_wide_bf16_body<RT, true>(g, blockIdx.y, blockIdx.x, sm);
+        classify_bwd_wide_bf16_body<T, RT, true>(g, blockIdx.y, blockIdx.x, sm);
         if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
             __syncthreads();
             loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
         }
     } else {
-        classify_bwd_wide_bf16_body<RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+        classify_bwd_wide_bf16_body<T, RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
     }
 }
 
@@ -148,9 +148,12 @@ static inline bool bwd_persistent(int64_t P) { return P >= 4; }       // quad lo
 #ifndef DENET_BWD_BF16_PIPE
 #define DENET_BWD_BF16_PIPE 1
 #endif
-// bf16 features with 32 < K <= 96 run B1 on the bf16 matrix pipe (its 16-byte Fq fragments need rows of >= 8)
+// B1 on the bf16 matrix pipe (dev_classify.hpp, classify_bwd_wide_bf16_body) for 32 < K <= 96, both feature types
+// (its 8-position Fq fragments need rows of >= 8).  K <= 32 stays on the fp32 instruction: there the operand
+// splits cost more than the cheaper MFMAs save (fp32 features, C2's shape: step 87.1 vs 86.3 us at 8 episodes,
+// 246 vs 242 at 32, 1025 vs 991 at 128).
 static inline bool bwd_bf16_pipe(int64_t K, int64_t P, size_t sF) {
-    return DENET_BWD_BF16_PIPE && sF == 2 && K > 32 && K <= 96 && P >= 8;
+    return DENET_BWD_BF16_PIPE && K > 32 && K <= 96 && P >= 8;
 }
 static inline bool bwd_dfq_nt(int64_t N, int64_t C, int64_t P, size_t sF) {
     return N * C * P * (int64_t)sF <= ((int64_t)DENET_DFQ_NT_MB << 20);
@@ -169,19 +172,19 @@ static inline bool dfs_chunked(bool nt, bool f32) { return DENET_DFS_CHUNKED && 
 template <typename T, int RT>
 static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float* part_p, int NB, int parts_p,
                           float* losses, int n_part, int N, bool wide, hipStream_t st) {
-    if constexpr (std::is_same<T, unsigned short>::value && (RT == 2 || RT == 3)) {
+    if constexpr (RT == 2 || RT == 3) {
         if (wide && bwd_bf16_pipe(g.K, g.P, sizeof(T))) {
             // (the finalize body of block (0, 0) reuses the LDS: both allocations are far above what it needs)
-            const size_t ldb = CLWB_LDS(RT);
+            const size_t ldb = CLWB_LDS(RT) > 4096 ? CLWB_LDS(RT) : 4096;
             if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
-                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<RT, true>), ldb))
+                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<T, RT, true>), ldb))
                     return DENET_E_LAUNCH;
-                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
                                    dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
             } else {
-                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<RT, false>), ldb))
+                if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<T, RT, false>), ldb))
                     return DENET_E_LAUNCH;
-                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
                                    dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
             }
             return DENET_OK;

@@ -305,7 +305,7 @@ typedef struct denet_step_plan {
     int32_t dfs_flat_writer;  /* fp32 + dfs_nt: B3 writes the block's 16 rows as one span instead of a row per wave */
     int32_t dfs_chunked;      /* bf16 + dfs_nt: B3's blocks only form coefficients, a second launch writes the flat
                                  tensor one contiguous chunk per block, in address order                              */
-    int32_t bwd_bf16_pipe;    /* bf16 features, 32 < K <= 96: B1 on the bf16 matrix pipe (dL as exact bf16 planes)     */
+    int32_t bwd_bf16_pipe;    /* 32 < K <= 96: B1 on the bf16 matrix pipe (dL, and fp32 Fq / Wn, as exact bf16 planes)   */
     int32_t reserved[1];
 } denet_step_plan_t;
 int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,

@@ -159,7 +159,7 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
     second on the host).  The launchers pick kernel variants from the sizes alone; the plan query reports what
     this shape runs, so the test fails if a threshold moves the benchmark onto a path it does not check:
     flat mask resize + non-temporal Fs loads (344 MB), classifier layout (a) with 12 blocks per episode,
-    chain loss kernel on 8-column cells, persistent backward with 6 tile groups, non-temporal dFq stores,
+    chain loss kernel on 8-column cells, persistent backward with 6 tile groups on the bf16 matrix pipe, non-temporal dFq stores,
     the flat non-temporal fp32 dFs writer."""
     from denet_amd import _lib
     from denet_amd.synthetic import CONFIGS
@@ -169,7 +169,7 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
     assert pl["pool_launches"] == 2 and pl["pool_nt_loads"] == 1 and pl["pool_long_rows"] == 0
     assert pl["classify_layout"] == _lib.CLS_UNITS and pl["classify_groups"] == 12
     assert pl["loss_chain_cell"] == 8 and 1 < (s.K + pl["loss_chunk"] - 1) // pl["loss_chunk"] <= 5
-    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 6 and pl["bwd_dfq_nt"] == 1
+    assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 6 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 1 and pl["dfs_chunked"] == 0
     _check_step_against_oracle(s, dev, 2e-5)
 
@@ -201,7 +201,7 @@ def test_c2_plan_at_the_headline_batch():
     pl = _plan(CONFIGS["C2"])
     assert pl["pool_launches"] == 1 and pl["pool_nt_loads"] == 0 and pl["classify_layout"] == _lib.CLS_TILE8
     assert pl["loss_chain_cell"] == 8 and pl["loss_chunk"] == 21
-    assert pl["bwd_groups"] == 14 and pl["dfs_nt"] == 0 and pl["bwd_dfq_nt"] == 1
+    assert pl["bwd_groups"] == 14 and pl["dfs_nt"] == 0 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 0
 
 
 @pytest.mark.parametrize("feat_dtype", ["f32", "bf16"])
