@@ -27,7 +27,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NAMES = [("wce_chain_pair_kernel", "loss_pair_fwd"), ("upsample_loss_pair_kernel", "loss_pair_fwd"),
-         ("wce_chain_kernel", "wce_fwd"), ("focal_kernel", "focal_fwd"), ("classify_fwd_wide4_kernel", "classify_fwd"), ("classify_fwd_wide4_bf16_kernel", "classify_fwd"), ("classify_fwd_wide_kernel", "classify_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"), ("head_bwd_dwn_wide_kernel", "bwd_dwn"),
+         ("wce_chain_kernel", "wce_fwd"), ("focal_kernel", "focal_fwd"), ("classify_fwd_wide4_kernel", "classify_fwd"), ("classify_fwd_wide4_bf16_kernel", "classify_fwd"), ("classify_fwd_wide_kernel", "classify_fwd"), ("head_bwd_dwn_kernel", "bwd_dwn"), ("head_bwd_dwn_wide_kernel", "bwd_dwn"), ("head_bwd_dwn_wide_bf16_kernel", "bwd_dwn"),
          ("head_bwd_mid_kernel", "bwd_chain_dfq"), ("head_bwd_tail_kernel", "bwd_params_dfs"),
          ("dfs_chunk_kernel", "dfs_chunk"), ("mask_resize_flat_kernel", "mask_resize"), ("mask_resize_kernel", "mask_resize"), ("masked_sum_fwd_kernel", "masked_pool_fwd"),
          ("proto_extend_fwd_kernel", "proto_extend_fwd"), ("gate_proj_kernel", "proto_extend_fwd"), ("classify_fwd_kernel", "classify_fwd"),
