@@ -588,6 +588,9 @@ def run(args):
             "roofline": roofline, "step_roofline": step_roof, "hbm_stream_kernels": streams,
             "hbm_copy_measured_gbs": copy_gbs, "cpu_baseline": cpu, "train_mode": train_line, "dropin": dropin,
             "kernels_us": {k: round(v, 2) for k, v in breakdown.items()},
+            # which variant each launch ran (denet_head_step_plan: the launchers' own decision functions)
+            "kernel_plan": _lib.head_step_plan(N, way, shape.shot, shape.K, shape.c, shape.h, shape.w, shape.H, shape.W,
+                                               _lib.BF16 if shape.feat_dtype == "bf16" else _lib.F32),
             "loss_k": losses[0], "loss_p": losses[1],
         }
         print(json.dumps(out), flush=True)

@@ -29,6 +29,8 @@ def test_bench_step_with_rccl_allreduce_one_rank():
         assert rf["bytes_per_launch"] == 40 * 256 * 1681 * 4 + 40 * 1681 * 8          # B*C*P*4 + B*P*8
     assert d["value_rotating"] is None or d["value_rotating"] > 0
     assert d["dropin"]["head_step_us_per_step"] > 0 and d["dropin"]["standalone_us_per_step"] > 0
+    # the variants the launchers chose for the benchmarked shape travel with the line
+    assert d["kernel_plan"]["pool_launches"] in (1, 2) and "classify_layout" in d["kernel_plan"]
     assert abs(d["loss_k"] - 3.109) < 0.01                     # the synthetic C2 batch: ln(21) = 3.04 plus noise
 
 
