@@ -85,7 +85,7 @@ class StepPlan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "pool_launches", "pool_long_rows", "pool_nt_loads", "classify_layout", "classify_groups",
         "loss_chain_cell", "loss_chunk", "loss_xsplit", "bwd_persistent", "bwd_groups", "bwd_dfq_nt",
-        "dfs_nt", "dfs_flat_writer", "dfs_chunked", "bwd_bf16_pipe")] + [("reserved", ctypes.c_int32 * 1)]
+        "dfs_nt", "dfs_flat_writer", "dfs_chunked", "bwd_bf16_pipe", "bwd_xcd_pairs")]
 
 
 CLS_TILE8, CLS_UNITS, CLS_WAVE4, CLS_WAVE4_BF16 = 0, 1, 2, 3

@@ -78,21 +78,55 @@ __global__ __launch_bounds__(64 * B1_NW) void head_bwd_dwn_kernel(ClsBwdArgs g, 
     }
 }
 
+// B1's persistent launches: the two roles of a tile group read the same dL tiles at the same time.  Workgroups go
+// to the 8 XCDs round-robin by linear id, so the (1-D) grid is laid out in runs of 8 dWn blocks followed by the 8
+// dFq blocks of the SAME (episode, group) pairs: both roles of a group share an XCD and the second reader of a dL
+// tile finds it in that XCD's L2.  The pairs are numbered through all episodes, so only the last run is padded
+// (a per-episode layout left two XCDs idle at C3's six groups: B1 37.7 -> 60.5 us).
+// Used while all blocks are resident at once (one round: both roles of a pair then run side by side; C3 B1 37.4 ->
+// 35.6 us, C5 41.4 -> 40.4, C2 14.8 -> 14.7); with several rounds of blocks it measured slower (C2 x 128: step
+// 1.000 vs 0.993 ms).
+#ifndef DENET_B1_XCD_PAIRS
+#define DENET_B1_XCD_PAIRS 1
+#endif
+static inline bool b1_paired(int ngrp, int N) { return DENET_B1_XCD_PAIRS && 2 * N * ngrp <= 320; }
+static inline dim3 b1_grid(int ngrp, int N) {
+    if (b1_paired(ngrp, N)) return dim3((unsigned)(((N * ngrp + 7) / 8) * 16));
+    return dim3((unsigned)(2 * ngrp), (unsigned)N);
+}
+__device__ __forceinline__ bool b1_role(int paired, int ngrp, int N, int& n, int& grp, bool& dwn) {
+    const int x = blockIdx.x;
+    if (paired) {
+        const int L = (x >> 4) * 8 + (x & 7);
+        dwn = ((x >> 3) & 1) == 0;
+        n = L / ngrp;
+        grp = L - n * ngrp;
+        return L < N * ngrp;
+    }
+    dwn = x < ngrp;
+    grp = dwn ? x : x - ngrp;
+    n = blockIdx.y;
+    return true;
+}
+
 // K > 32: persistent blocks (dev_classify.hpp, classify_bwd_wide_body); g.n_part = groups per episode
 template <typename T, int RT, bool NTQ>
 __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsBwdArgs g, ClsBwdArgs g2,
                                                                             const float* __restrict__ part_p, int NB,
-                                                                            int parts_p, float* __restrict__ losses) {
+                                                                            int parts_p, float* __restrict__ losses,
+                                                                            int paired) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ngrp = g.n_part;
-    if ((int)blockIdx.x < ngrp) {
-        classify_bwd_wide_body<T, RT, true>(g, blockIdx.y, blockIdx.x, sm);
-        if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    int n, grp;
+    bool dwn;
+    if (!b1_role(paired, g.n_part, g.N, n, grp, dwn)) return;
+    if (dwn) {
+        classify_bwd_wide_body<T, RT, true>(g, n, grp, sm);
+        if (losses != nullptr && grp == 0 && n == 0) {
             __syncthreads();
             loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
         }
     } else {
-        classify_bwd_wide_body<T, RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+        classify_bwd_wide_body<T, RT, false, NTQ>(g2, n, grp, sm);
     }
 }
 
@@ -100,17 +134,20 @@ __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_kernel(ClsB
 template <typename T, int RT, bool NTQ>
 __global__ __launch_bounds__(64 * CLW_BWD_NW) void head_bwd_dwn_wide_bf16_kernel(ClsBwdArgs g, ClsBwdArgs g2,
                                                                                  const float* __restrict__ part_p, int NB,
-                                                                                 int parts_p, float* __restrict__ losses) {
+                                                                                 int parts_p, float* __restrict__ losses,
+                                                                                 int paired) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ngrp = g.n_part;
-    if ((int)blockIdx.x < ngrp) {
-        classify_bwd_wide_bf16_body<T, RT, true>(g, blockIdx.y, blockIdx.x, sm);
-        if (losses != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    int n, grp;
+    bool dwn;
+    if (!b1_role(paired, g.n_part, g.N, n, grp, dwn)) return;
+    if (dwn) {
+        classify_bwd_wide_bf16_body<T, RT, true>(g, n, grp, sm);
+        if (losses != nullptr && grp == 0 && n == 0) {
             __syncthreads();
             loss_finalize_body(g.part_k, part_p, g.N, NB, g.parts_k, parts_p, 0, losses, nullptr, nullptr, sm);
         }
     } else {
-        classify_bwd_wide_bf16_body<T, RT, false, NTQ>(g2, blockIdx.y, blockIdx.x - ngrp, sm);
+        classify_bwd_wide_bf16_body<T, RT, false, NTQ>(g2, n, grp, sm);
     }
 }
 
@@ -179,13 +216,13 @@ static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float
             if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
                 if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<T, RT, true>), ldb))
                     return DENET_E_LAUNCH;
-                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
-                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, true>), b1_grid(n_part, N),
+                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses, (int)b1_paired(n_part, N));
             } else {
                 if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_bf16_kernel<T, RT, false>), ldb))
                     return DENET_E_LAUNCH;
-                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
-                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses);
+                hipLaunchKernelGGL((head_bwd_dwn_wide_bf16_kernel<T, RT, false>), b1_grid(n_part, N),
+                                   dim3(64 * CLW_BWD_NW), ldb, st, g, g2, part_p, NB, parts_p, losses, (int)b1_paired(n_part, N));
             }
             return DENET_OK;
         }
@@ -195,13 +232,13 @@ static int launch_bwd_dwn(const ClsBwdArgs& g, const ClsBwdArgs& g2, const float
         if (bwd_dfq_nt(N, g.C, g.P, sizeof(T))) {
             if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT, true>), ldw))
                 return DENET_E_LAUNCH;
-            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, true>), dim3((unsigned)(2 * n_part), (unsigned)N),
-                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, true>), b1_grid(n_part, N),
+                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses, (int)b1_paired(n_part, N));
         } else {
             if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_dwn_wide_kernel<T, RT, false>), ldw))
                 return DENET_E_LAUNCH;
-            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, false>), dim3((unsigned)(2 * n_part), (unsigned)N),
-                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses);
+            hipLaunchKernelGGL((head_bwd_dwn_wide_kernel<T, RT, false>), b1_grid(n_part, N),
+                               dim3(64 * CLW_BWD_NW), ldw, st, g, g2, part_p, NB, parts_p, losses, (int)b1_paired(n_part, N));
         }
         return DENET_OK;
     }
@@ -298,6 +335,7 @@ extern "C" int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_
     p.bwd_groups = p.bwd_persistent ? cls_bwd_wide_groups(N, P, RT) : (int)denet_classify_bwd_parts(P);
     p.bwd_dfq_nt = p.bwd_persistent && bwd_dfq_nt(N, C, P, sF);
     p.bwd_bf16_pipe = p.bwd_persistent && bwd_bf16_pipe(K, P, sF);
+    p.bwd_xcd_pairs = p.bwd_persistent && b1_paired(p.bwd_groups, (int)N);
     p.dfs_nt = dfs_nt(B, C, P, sF);
     // non-temporal streams: fp32 = the flat span writer inside B3, bf16 = coefficient blocks + dfs_chunk_kernel
     p.dfs_chunked = dfs_chunked(p.dfs_nt, sF == 4);

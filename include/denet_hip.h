@@ -306,7 +306,7 @@ typedef struct denet_step_plan {
     int32_t dfs_chunked;      /* bf16 + dfs_nt: B3's blocks only form coefficients, a second launch writes the flat
                                  tensor one contiguous chunk per block, in address order                              */
     int32_t bwd_bf16_pipe;    /* 32 < K <= 96: B1 on the bf16 matrix pipe (dL, and fp32 Fq / Wn, as exact bf16 planes)   */
-    int32_t reserved[1];
+    int32_t bwd_xcd_pairs;    /* B1's grid pairs the two roles of a tile group on one XCD (one-round grids only)        */
 } denet_step_plan_t;
 int denet_head_step_plan(int64_t N, int64_t way, int64_t shot, int64_t K, int64_t C, int64_t h, int64_t w,
                          int64_t H, int64_t W, int feat_dtype, denet_step_plan_t* out);

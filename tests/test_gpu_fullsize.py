@@ -170,6 +170,7 @@ def test_c3_fwd_bwd_at_the_benchmarked_batch(dev):
     assert pl["classify_layout"] == _lib.CLS_UNITS and pl["classify_groups"] == 12
     assert pl["loss_chain_cell"] == 8 and 1 < (s.K + pl["loss_chunk"] - 1) // pl["loss_chunk"] <= 5
     assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 6 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 1
+    assert pl["bwd_xcd_pairs"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 1 and pl["dfs_chunked"] == 0
     _check_step_against_oracle(s, dev, 2e-5)
 
@@ -188,6 +189,7 @@ def test_c5_at_the_benchmarked_batch(dev):
     assert pl["classify_layout"] == _lib.CLS_WAVE4_BF16
     assert pl["loss_chain_cell"] == 9
     assert pl["bwd_persistent"] == 1 and pl["bwd_groups"] == 15 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 1
+    assert pl["bwd_xcd_pairs"] == 1
     assert pl["dfs_nt"] == 1 and pl["dfs_flat_writer"] == 0 and pl["dfs_chunked"] == 1
     ep, out = _check_step_against_oracle(s, dev, 8e-3)
     assert out["Fs"].grad.dtype == torch.bfloat16
@@ -202,6 +204,7 @@ def test_c2_plan_at_the_headline_batch():
     assert pl["pool_launches"] == 1 and pl["pool_nt_loads"] == 0 and pl["classify_layout"] == _lib.CLS_TILE8
     assert pl["loss_chain_cell"] == 8 and pl["loss_chunk"] == 21
     assert pl["bwd_groups"] == 14 and pl["dfs_nt"] == 0 and pl["bwd_dfq_nt"] == 1 and pl["bwd_bf16_pipe"] == 0
+    assert pl["bwd_xcd_pairs"] == 1
 
 
 @pytest.mark.parametrize("feat_dtype", ["f32", "bf16"])
