@@ -163,13 +163,20 @@ __global__ __launch_bounds__(SC_THREADS) void head_bwd_mid_kernel(ChainMidArgs a
 
 template <typename T, int NSLT, bool NT>
 __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, CoefArgs ca, const float* __restrict__ mask,
-                                                           T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx) {
+                                                           T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx,
+                                                           int pfirst) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bx = blockIdx.x, nms = gridDim.x - 3 * gx;
-    if (bx < nms) {
-        masked_sum_bwd_body<T, NSLT, NT>(mask, nullptr, dFs, C, P, rpb, bx / ncb, bx % ncb, sm, ca);
+    // pfirst: the parameter-gradient blocks come FIRST in the grid.  They loop over all B images (21 us at C3's
+    // 200) and, dispatched behind the dFs blocks of a long stream, they started when it was nearly written and ran on
+    // past its end (C3 step 320.8 -> 319.6 us, C2 x 128 991 -> 979).  A short stream they would only delay (C2 at 8
+    // episodes: 86.1 -> 88.1 us), so the launcher asks for it with the non-temporal streams (> 80 MB) only.
+    const int bx = blockIdx.x, npar = 3 * gx, nms = gridDim.x - npar;
+    const bool par = pfirst ? bx < npar : bx >= nms;
+    if (!par) {
+        const int d = pfirst ? bx - npar : bx;
+        masked_sum_bwd_body<T, NSLT, NT>(mask, nullptr, dFs, C, P, rpb, d / ncb, d % ncb, sm, ca);
     } else {
-        const int r = bx - nms;
+        const int r = pfirst ? bx : bx - nms;
         proto_extend_bwd_params_body(pa, r / gx, r % gx, sm);
     }
 }
@@ -541,12 +548,12 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, true>), lds))     \
             return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, true>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs,  \
-                           (int)C, (int)P, rpb, ncb, gx);                                                           \
+                           (int)C, (int)P, rpb, ncb, gx, (int)nt);                                                         \
     } else {                                                                                                        \
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, false>), lds))    \
             return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, false>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, \
-                           (int)C, (int)P, rpb, ncb, gx);                                                           \
+                           (int)C, (int)P, rpb, ncb, gx, (int)nt);                                                         \
     }
         if (f32) {
             if (C == 256) { TAIL_GO(float, 16); } else { TAIL_GO(float, 4); }
@@ -562,6 +569,8 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
 #ifndef DENET_DFS_CHUNK_U_BF16
 #define DENET_DFS_CHUNK_U_BF16 2
 #endif
+            // (the parameter-gradient blocks were also tried inside this launch, where a 48 us stream would hide their
+            // 10.5 us: the combined kernel's register count cuts the chunk blocks' occupancy, C5 B3 60.5 -> 68 us)
             const int64_t span = C * P;
             if (f32) {
                 constexpr int U = DENET_DFS_CHUNK_U_F32;
