@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
                                                            T* __restrict__ dFs, int C, int P, int rpb, int ncb, int gx,
                                                            int pfirst) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // pfirst: the parameter-gradient blocks come FIRST in the grid.  They loop over all B images (21 us at C3's
-    // 200) and, dispatched behind the dFs blocks of a long stream, they started when it was nearly written and ran on
-    // past its end (C3 step 320.8 -> 319.6 us, C2 x 128 991 -> 979).  A short stream they would only delay (C2 at 8
-    // episodes: 86.1 -> 88.1 us), so the launcher asks for it with the non-temporal streams (> 80 MB) only.
+    // pfirst: the parameter-gradient blocks come FIRST in the grid.  They loop over all B support images and,
+    // dispatched behind the dFs blocks of a long stream, they start when it is nearly written and run on past its
+    // end.  Step time first / last: 640 images (C2 x 128) 979 / 991 us, 200 (C3) 319.6 / 320.8, 160 (C2 x 32)
+    // 247.0 / 243.5, 80 (C2 x 16) 147.8 / 143.3, 40 (C2) 88.1 / 86.1 -- first pays only where the loops are long, so
+    // the launcher asks for it from 320 images on.
     const int bx = blockIdx.x, npar = 3 * gx, nms = gridDim.x - npar;
     const bool par = pfirst ? bx < npar : bx >= nms;
     if (!par) {
@@ -181,6 +182,9 @@ __global__ __launch_bounds__(256) void head_bwd_tail_kernel(PeParamsArgs pa, Coe
     }
 }
 
+#ifndef DENET_TAIL_PARAMS_FIRST_B
+#define DENET_TAIL_PARAMS_FIRST_B 320   // B3: parameter-gradient blocks first from this many support images on (see the kernel)
+#endif
 #ifndef DENET_DFS_NT_MB
 #define DENET_DFS_NT_MB 80          // dFs streams above this size leave with non-temporal stores (see B3 below)
 #endif
@@ -548,12 +552,12 @@ extern "C" int denet_head_step_train_bwd(const void* Fq, int feat_dtype, const i
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, true>), lds))     \
             return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, true>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs,  \
-                           (int)C, (int)P, rpb, ncb, gx, (int)nt);                                                         \
+                           (int)C, (int)P, rpb, ncb, gx, (int)(nt && B >= DENET_TAIL_PARAMS_FIRST_B));                                                         \
     } else {                                                                                                        \
         if (denet_ensure_dynamic_lds(reinterpret_cast<const void*>(head_bwd_tail_kernel<TT, NSLT, false>), lds))    \
             return DENET_E_LAUNCH;                                                                                  \
         hipLaunchKernelGGL((head_bwd_tail_kernel<TT, NSLT, false>), grid, block, lds, st, pa, ca, s.mask, (TT*)dFs, \
-                           (int)C, (int)P, rpb, ncb, gx, (int)nt);                                                         \
+                           (int)C, (int)P, rpb, ncb, gx, (int)(nt && B >= DENET_TAIL_PARAMS_FIRST_B));                                                         \
     }
         if (f32) {
             if (C == 256) { TAIL_GO(float, 16); } else { TAIL_GO(float, 4); }
