@@ -55,6 +55,11 @@ struct ClsBwdArgs {
 #define CLS_BWD_LDS_NW(K, NW) ((size_t)(CLS_BWD_DL(K) + (NW) * 32 * CL_TS) * 4)
 #define CLS_BWD_LDS(K) CLS_BWD_LDS_NW(K, 4)
 
+// 1 / (N * den) for the episode's gradient; 0 when every label pixel of the episode is ignored (den == 0): the
+// reference's loss is 0/0 = NaN there while its gradient is exactly zero (nll_loss's backward skips ignored targets,
+// trainer/utils.py:272-277 + ATen), and inf * 0 would make ours NaN
+__device__ __forceinline__ float episode_scale(int N, float den) { return den > 0.f ? 1.f / ((float)N * den) : 0.f; }
+
 // 1/(N * sum of the episode's den partials): every lane of the calling wave gets the value
 __device__ __forceinline__ float episode_den(const float* __restrict__ part_k, int parts_k, int n) {
     float de = 0.f;
@@ -152,7 +157,7 @@ __device__ __forceinline__ void classify_bwd_body(const ClsBwdArgs& g, int n, in
     }
     float sc;
     if (g.part_k != nullptr) {
-        sc = 1.f / ((float)g.N * episode_den(g.part_k, g.parts_k, n));
+        sc = episode_scale(g.N, episode_den(g.part_k, g.parts_k, n));
         if (g.scale_out != nullptr && tile == 0 && tid == 0) g.scale_out[n] = sc;
     } else {
         sc = g.scale ? g.scale[n] : 1.f;
@@ -439,7 +444,7 @@ __device__ __forceinline__ void classify_bwd_wide_body(const ClsBwdArgs& g, int 
     }
     float sc;
     if (g.part_k != nullptr) {
-        sc = 1.f / ((float)g.N * wave_sum(de));
+        sc = episode_scale(g.N, wave_sum(de));
         if (g.scale_out != nullptr && grp == 0 && tid == 0) g.scale_out[n] = sc;
     } else {
         sc = g.scale ? g.scale[n] : 1.f;
@@ -813,7 +818,7 @@ __device__ __forceinline__ void classify_bwd_wide_bf16_body(const ClsBwdArgs& g,
     }
     float sc;
     if (g.part_k != nullptr) {
-        sc = 1.f / ((float)g.N * wave_sum(de));
+        sc = episode_scale(g.N, wave_sum(de));
         if (g.scale_out != nullptr && grp == 0 && tid == 0) g.scale_out[n] = sc;
     } else {
         sc = g.scale ? g.scale[n] : 1.f;

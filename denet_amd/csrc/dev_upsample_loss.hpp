@@ -382,7 +382,7 @@ __device__ __forceinline__ void loss_finalize_body(const float* __restrict__ par
             const float l = nu / de;
             if (lane == 0) {
                 if (per_episode) per_episode[n] = l;
-                if (scale) scale[n] = 1.f / ((float)N * de);
+                if (scale) scale[n] = de > 0.f ? 1.f / ((float)N * de) : 0.f;     // (all pixels ignored: zero gradient, as the reference)
                 ls += l;
             }
         }
@@ -400,7 +400,7 @@ __device__ __forceinline__ void loss_finalize_body(const float* __restrict__ par
         de = block_sum(de, red);
         if (tid == 0) out[0] = nu / de;
         if (scale)
-            for (int n = tid; n < N; n += nt) scale[n] = 1.f / de;
+            for (int n = tid; n < N; n += nt) scale[n] = de > 0.f ? 1.f / de : 0.f;
         if (per_episode)
             for (int n = tid; n < N; n += nt) per_episode[n] = nu / de;
     }

@@ -340,3 +340,34 @@ def test_classifier_on_the_bf16_matrix_pipe(N, way, K, C, h, w, base, feat, dev)
     # the shared-weight entry point (mode='deploy', model/common.py:369-372) takes the same kernel
     sh = ops.classify_shared(Fq.to(dev), Wn[0].to(dev))
     assert rel_err(sh.cpu(), O.classify(Fq.double(), Wn[:1].double().expand(N, K, C))) < 2e-6
+
+
+def test_episode_with_every_label_ignored(dev):
+    """An episode whose whole query map is the ignore label: the reference's per-episode CE is 0 / 0 = NaN
+    (trainer/utils.py:272-277) while its gradient is exactly zero -- ATen's nll_loss backward skips ignored targets,
+    so nothing is multiplied by the infinite 1 / den.  The fused step must not turn that into NaN gradients for
+    the OTHER episodes of the batch (parameter gradients sum over episodes)."""
+    from denet_amd import ops
+    from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state
+    from oracle import denet_oracle as O
+    order = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias"]
+    for K in (21, 81):                                   # both backward kernels (fp32 instruction / bf16 pipe)
+        s = EpisodeShape("ign", N=3, way=1, shot=2, K=K, c=64, h=9, w=10, H=33, W=37, config_index=55, lam=1.0)
+        ep = make_episodes(s, ignore_rows=2)
+        ep["Yq_full"][1] = 255                           # episode 1: nothing to learn from
+        state = make_estimator_state(s.K, s.c)
+        P = [state[k].to(dev).requires_grad_(True) for k in order]
+        Fq = ep["Fq"].to(dev).requires_grad_(True)
+        Fs = ep["Fs"].to(dev).requires_grad_(True)
+        lk, lp, logits, binl = ops.HeadStepFunction.apply(
+            Fq, Fs, *P, ep["Ys"].to(dev), ep["label"].reshape(s.N, 1).to(dev), ep["Yq"].to(dev),
+            ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+        lk.backward()
+        ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+        assert torch.isnan(ref["loss_k"]) and torch.isnan(lk)                      # the loss is NaN on both sides
+        assert not torch.isnan(ref["dFq"]).any()
+        assert rel_err(Fq.grad.cpu(), ref["dFq"]) < TIGHT and rel_err(Fs.grad.cpu(), ref["dFs"]) < TIGHT
+        assert float(Fq.grad[1].abs().max()) == 0.0                                # the ignored episode: exactly zero
+        for k, t in zip(order, P):
+            assert rel_err(t.grad.cpu(), ref["d:" + k]) < TIGHT, k
