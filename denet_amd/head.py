@@ -270,8 +270,7 @@ class WeightEstimator(nn.Module):
                 self.last_dropout_seed = drop[0]
         wgt = None if weight is None else weight.to(Fs.device, torch.float32).reshape(N, self.num_classes).contiguous()
         Yq2 = None if Yq is None else Yq.reshape(N * way, *Yq.shape[-2:])
-        return ops.HeadStepFunction.apply(embedding, Fs, *self._params(), Ys, labels, Yq2, Yq_full, wgt,
-                                          gate_mask, weight_mask, drop)
+        return ops.head_step(embedding, Fs, *self._params(), Ys, labels, Yq2, Yq_full, wgt, gate_mask, weight_mask, drop)
 
 
 # ------------------------------------------------------------------------------------------

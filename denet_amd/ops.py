@@ -509,7 +509,7 @@ class HeadStepFunction(torch.autograd.Function):
         H, W = Ys.shape[-2:]
         Yq = _as_i64(Yq).contiguous() if Yq is not None else None
         Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
-        need = any(ctx.needs_input_grad[:9])          # (false under no_grad as well: validation steps)
+        need = any(ctx.needs_input_grad[:9])          # (ops.head_step detaches the inputs under no_grad)
         nbytes = _step_workspace_bytes(N, way, shot, K, C, h, w, H, W)
         ws_key, ws = workspace_pool.take(nbytes, dev)
         logits = _f32(N, K, h, w, device=dev)
@@ -563,6 +563,16 @@ class HeadStepFunction(torch.autograd.Function):
         workspace_pool.give(ctx.ws_key, ctx.ws)
         ctx.ws = None
         return (dFq, dFs, dweight, dW1, db1, dW2, db2, dWl, dbl) + (None,) * 8
+
+
+def head_step(*args):
+    """HeadStepFunction.apply for callers that may run under torch.no_grad() (validation steps).  Inside an autograd
+    Function's forward the grad mode is always off and `ctx.needs_input_grad` still mirrors the inputs'
+    requires_grad, so the node cannot see a surrounding no_grad by itself: it would write the gradient slabs
+    nobody reads and keep its workspace out of the pool.  Detached inputs say what the caller means."""
+    if not torch.is_grad_enabled():
+        args = tuple(a.detach() if isinstance(a, torch.Tensor) else a for a in args)
+    return HeadStepFunction.apply(*args)
 
 
 def head_forward(Fq, Fs, params, Ys, labels, gate_mask=None, weight_mask=None, drop=None):

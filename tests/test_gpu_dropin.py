@@ -73,6 +73,14 @@ def test_forward_step_is_one_fused_node_and_matches_the_reference(name, dev):
                                             ep["wgt"].to(dev))
     assert lk3.grad_fn is None and torch.equal(full3, full) and rel_err(lk3.cpu(), lk.detach().cpu()) < 1e-6
     assert sum(len(v) for v in ops.workspace_pool._free.values()) >= 1
+    # ... also when this is the process's first step (nothing left in the pool by earlier tests): the node sees the
+    # surrounding no_grad (ops.head_step), runs the forward without gradient slabs and hands its workspace back
+    ops.workspace_pool.clear()
+    with torch.no_grad():
+        lk4, _, full4, _ = m.forward_step(Fs, ep["Ys"].to(dev), Fq, lab, ep["Yq"].to(dev), ep["Yq_full"].to(dev),
+                                          ep["wgt"].to(dev))
+    assert lk4.grad_fn is None and torch.equal(full4, full) and rel_err(lk4.cpu(), lk.detach().cpu()) < 1e-6
+    assert sum(len(v) for v in ops.workspace_pool._free.values()) == 1
 
 
 def test_train_mode_forward_step_draws_in_kernel_dropout(dev):
@@ -238,3 +246,43 @@ def test_standalone_pooling_long_rows_fp32(dev):
     S = ops.masked_sum(Fs.to(dev), mask.to(dev))
     ref = (Fs.reshape(B, C, -1).double() * mask.unsqueeze(1).double()).sum(-1)
     assert rel_err(S.cpu(), ref) < 2e-6
+
+
+def test_head_step_follows_the_callers_stream(dev):
+    """The library launches on the stream torch has current (denet_amd._lib.current_stream_handle), forward AND
+    backward (autograd runs the backward node under the forward's stream).  The inputs are produced on a side
+    stream BEHIND a few milliseconds of other work and consumed there at once: kernels launched on any other
+    stream would read the zeros the buffers held before."""
+    from denet_amd import ops
+    from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state
+    from oracle import denet_oracle as O
+    order = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias"]
+    s = EpisodeShape("side", N=2, way=1, shot=3, K=21, c=64, h=17, w=19, H=65, W=73, config_index=31, lam=1.0)
+    ep = make_episodes(s, ignore_rows=2)
+    state = make_estimator_state(s.K, s.c)
+    ref = O.head_step(ep["Fq"], ep["Fs"], ep["Ys"], ep["label"], ep["Yq"], ep["Yq_full"], ep["wgt"], state)
+    pinned = {k: ep[k].pin_memory() for k in ("Fq", "Fs")}
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        Fq = torch.zeros_like(ep["Fq"], device=dev)
+        Fs = torch.zeros_like(ep["Fs"], device=dev)
+        busy = torch.randn(4096, 4096, device=dev)
+        for _ in range(20):                                   # ~ms of work in front of the copies
+            busy = busy @ busy * 1e-4
+        Fq.copy_(pinned["Fq"], non_blocking=True)
+        Fs.copy_(pinned["Fs"], non_blocking=True)
+        Fq.requires_grad_(True)
+        Fs.requires_grad_(True)
+        P = [state[k].to(dev).requires_grad_(True) for k in order]
+        lk, lp, logits, binl = ops.HeadStepFunction.apply(
+            Fq, Fs, *P, ep["Ys"].to(dev), ep["label"].reshape(s.N, 1).to(dev), ep["Yq"].to(dev),
+            ep["Yq_full"].to(dev), ep["wgt"].to(dev), None, None)
+        lk.backward()
+    side.synchronize()
+    assert rel_err(logits.cpu(), ref["logits_full"]) < 2e-5
+    assert rel_err(lk.detach().cpu(), ref["loss_k"]) < 1e-4
+    assert rel_err(Fq.grad.cpu(), ref["dFq"]) < 2e-5 and rel_err(Fs.grad.cpu(), ref["dFs"]) < 2e-5
+    for k, t in zip(order, P):
+        assert rel_err(t.grad.cpu(), ref["d:" + k]) < 2e-5, k
