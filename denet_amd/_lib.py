@@ -170,11 +170,21 @@ def current_stream_handle(device_index=None) -> int:
 
 
 def call(name: str, *args):
-    """Enqueue `name` on torch's current stream; raise on a non-zero code."""
+    """Enqueue `name` on torch's current stream of the device the tensors live on; raise on a non-zero code.
+    (A kernel launch goes to the calling thread's CURRENT device: tensors of another device -- a process that
+    drives several GPUs without torch.cuda.set_device -- are launched under that device's guard.)"""
     lib = load()
     conv = _convert(name, args)
-    stream = current_stream_handle()
-    rc = getattr(lib, name)(*conv, stream)
+    di = -1
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            di = a.get_device()
+            break
+    if di >= 0 and di != torch.cuda.current_device():
+        with torch.cuda.device(di):
+            rc = getattr(lib, name)(*conv, current_stream_handle(di))
+    else:
+        rc = getattr(lib, name)(*conv, current_stream_handle())
     if rc != 0:
         raise DenetHipError(f"{name} failed: {strerror(rc)} (code {rc})")
 

@@ -82,6 +82,12 @@ class HeadStepEngine:
         """The pre-converted calls of one step on these input tensors (outputs, gradients and workspace are the
         engine's own): what bind_step installs."""
         N, way, shot, K, C, h, w, H, W = self.dims
+        # the pre-bound calls launch on the calling thread's current device with no per-step check (they are the
+        # 90 us loop): refuse to bind while another device is current
+        dev_index = torch.device(self.device).index
+        if dev_index is not None and dev_index != torch.cuda.current_device():
+            raise _lib.DenetHipError(f"HeadStepEngine on cuda:{dev_index} bound while cuda:{torch.cuda.current_device()} "
+                                     "is the current device: torch.cuda.set_device first (one process per GPU)")
         P = [params[k] for k in PARAM_ORDER]
         deferred = Yq_full is not None
         have_focal = Yq is not None
