@@ -456,6 +456,33 @@ def _step_workspace_bytes(*dims):
     return n
 
 
+def _check_step_shapes(Fq, Fs, params, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask):
+    """The kernels index raw memory from (N, way, shot, K, C, h, w, H, W) alone: a tensor of another size is an
+    out-of-bounds access on the GPU, so the sizes are checked on the host (element counts: views are fine)."""
+    N, way, shot, C, h, w = Fs.shape
+    K = params[0].shape[0]
+    H, W = Ys.shape[-2:]
+
+    def need(name, t, numel, tail=None):
+        if t is None:
+            return
+        if t.numel() != numel or (tail is not None and tuple(t.shape[-len(tail):]) != tuple(tail)):
+            raise ValueError(f"head step: {name} has shape {tuple(t.shape)}, expected {numel} elements"
+                             + (f" ending in {tuple(tail)}" if tail is not None else ""))
+    need("Fq", Fq, N * C * h * w, (C, h, w))
+    need("Ys", Ys, N * way * shot * H * W)
+    need("labels", labels, N * way)
+    # one (H, W) describes all three label maps (the reference's loader crops them alike)
+    need("Yq", Yq, N * way * H * W, (H, W))
+    need("Yq_full", Yq_full, N * H * W, (H, W))
+    need("weight (loss class weights)", wgt, N * K)
+    for name, t, shp in zip(("weight", "W1", "b1", "W2", "b2", "Wl", "bl"), params,
+                            ((K, C), (C, C), (C,), (C, C), (C,), (C, C), (C,))):
+        need(name, t, int(torch.Size(shp).numel()))          # (the gate's 1x1 convolutions hold [C, C, 1, 1])
+    need("gate_mask", gate_mask, N * way * shot * C)
+    need("weight_mask", weight_mask, N * K * C)
+
+
 class _WorkspacePool:
     """Step workspaces by (device, stream, bytes): the fused step's scratch slab (~150 MB at C2) is handed from
     one step to the next instead of going through the allocator on every call.  A forward takes a slab, the
@@ -509,6 +536,7 @@ class HeadStepFunction(torch.autograd.Function):
         H, W = Ys.shape[-2:]
         Yq = _as_i64(Yq).contiguous() if Yq is not None else None
         Yq_full = _as_i64(Yq_full).contiguous() if Yq_full is not None else None
+        _check_step_shapes(Fq, Fs, params, Ys, labels, Yq, Yq_full, wgt, gate_mask, weight_mask)
         need = any(ctx.needs_input_grad[:9])          # (ops.head_step detaches the inputs under no_grad)
         nbytes = _step_workspace_bytes(N, way, shot, K, C, h, w, H, W)
         ws_key, ws = workspace_pool.take(nbytes, dev)
@@ -588,6 +616,7 @@ def head_forward(Fq, Fs, params, Ys, labels, gate_mask=None, weight_mask=None, d
     labels = _as_i64(labels).contiguous()
     Ys = _as_i64(Ys).contiguous()
     H, W = Ys.shape[-2:]
+    _check_step_shapes(Fq, Fs, params, Ys, labels, None, None, None, gate_mask, weight_mask)
     nbytes = _step_workspace_bytes(N, way, shot, K, C, h, w, H, W)
     ws_key, ws = workspace_pool.take(nbytes, dev)
     logits = _f32(N, K, h, w, device=dev)

@@ -286,3 +286,34 @@ def test_head_step_follows_the_callers_stream(dev):
     assert rel_err(Fq.grad.cpu(), ref["dFq"]) < 2e-5 and rel_err(Fs.grad.cpu(), ref["dFs"]) < 2e-5
     for k, t in zip(order, P):
         assert rel_err(t.grad.cpu(), ref["d:" + k]) < 2e-5, k
+
+
+def test_head_step_rejects_mismatched_shapes(dev):
+    """The kernels index raw memory from the step's sizes; a tensor of another size must be refused on the host
+    (ValueError) instead of being read out of bounds: label maps of another size than Ys, a short weight vector,
+    a feature map of another channel count."""
+    from denet_amd import ops
+    from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state
+    order = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+             "map.linear.weight", "map.linear.bias"]
+    s = EpisodeShape("chk", N=2, way=1, shot=2, K=21, c=64, h=9, w=11, H=33, W=41, config_index=5, lam=1.0)
+    ep = {k: v.to(dev) for k, v in make_episodes(s, ignore_rows=1).items()}
+    P = [v.to(dev) for v in (make_estimator_state(s.K, s.c)[k] for k in order)]
+    lab = ep["label"].reshape(s.N, 1)
+
+    def run(**over):
+        a = dict(Fq=ep["Fq"], Fs=ep["Fs"], Ys=ep["Ys"], Yq=ep["Yq"], Yq_full=ep["Yq_full"], wgt=ep["wgt"], P=P)
+        a.update(over)
+        return ops.head_step(a["Fq"], a["Fs"], *a["P"], a["Ys"], lab, a["Yq"], a["Yq_full"], a["wgt"], None, None)
+
+    run()                                                                   # the matching shapes pass
+    with pytest.raises(ValueError, match="Yq_full"):
+        run(Yq_full=ep["Yq_full"][:, :-1])
+    with pytest.raises(ValueError, match="Yq"):
+        run(Yq=ep["Yq"][..., :-2])
+    with pytest.raises(ValueError, match="class weights"):
+        run(wgt=ep["wgt"][:, :-1])
+    with pytest.raises(ValueError, match="Fq"):
+        run(Fq=ep["Fq"][:, :32])
+    with pytest.raises(ValueError, match="W2"):
+        run(P=P[:3] + [P[3][:, :32]] + P[4:])
