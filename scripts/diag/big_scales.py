@@ -13,7 +13,9 @@ from helpers import rel_err                                     # noqa: E402
 from denet_amd import ops, _lib                                 # noqa: E402
 from denet_amd.synthetic import EpisodeShape, make_episodes, make_estimator_state   # noqa: E402
 from oracle import denet_oracle as O                            # noqa: E402  (checker)
-from fuzz_parity_order import ORDER                             # noqa: E402
+
+ORDER = ["weight", "gam.gate.0.weight", "gam.gate.0.bias", "gam.gate.2.weight", "gam.gate.2.bias",
+         "map.linear.weight", "map.linear.bias"]
 
 dev = torch.device("cuda:0")
 bad = 0
