@@ -43,6 +43,6 @@ for i, (h, w, H, W, K) in enumerate([(21, 21, 321, 321, 21), (11, 11, 321, 321, 
             "logits": rel_err(logits.cpu(), ref["logits_full"])}
     ok = all(v < 1e-3 for v in errs.values())
     bad += not ok
-    print(f"{h}x{w}->{H}x{W} K={K}: max={max(errs.values()):.2e}" + ("" if ok else f" FAIL {errs}"), flush=True)
+    print(f"{h}x{w}->{H}x{W} K={K}: max={max(errs.values()):.2e} ({max(errs, key=errs.get)})" + ("" if ok else f" FAIL {errs}"), flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
